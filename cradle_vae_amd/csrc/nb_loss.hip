@@ -1,0 +1,312 @@
+// K1: library-size negative-binomial (Gamma-Poisson) log-likelihood over genes, fused with
+// the row softmax that produces the mean, the gene reduction, and (training) the backward
+// pass to the decoder logits and to log_concentration.
+//
+// Reference chain this replaces (all paths relative to /root/reference):
+//   cradle_vae/models/utils/mlp.py:153-166   softmax -> mu = lib*softmax -> rate = clamp(c/(mu+1e-4), 1e-6)
+//   pyro GammaPoisson.log_prob (pyro-ppl 1.9.1) called at cradle_vae/models/utils/loss_modules.py:134-135
+//   cradle_vae/models/utils/loss_modules.py:143  .sum(-1) over genes
+//
+// HBM-bound streaming kernel.  One workgroup owns one cell n: the count row X[n,:], the
+// per-gene concentration and the per-gene lgamma/digamma terms (which depend only on
+// (n,g), not on the particle) stay in registers while the workgroup walks the particle
+// rows p of that cell; the next row's logits are prefetched while the current one is
+// reduced.  Every logit is read from HBM exactly once and (training) overwritten in place
+// by its gradient.
+#include "common.h"
+#include "nb_math.h"
+
+namespace cradle {
+
+template <int VPT, int NT, bool BWD>
+__global__ __launch_bounds__(NT) void nb_rows_kernel(
+    const float* logits, int64_t ld_logits,       // (P*N, ld) rows r = p*N + n
+    float* dlogits, int64_t ld_dlogits,           // BWD: gradient rows, may alias logits
+    const float* __restrict__ X, int64_t ldx,     // (N, ldx) integer-valued counts
+    const float* __restrict__ lib,                // (N) library sizes
+    const float* __restrict__ gene_consts,        // (3, G): c, lgamma(c), digamma(c)
+    const float* __restrict__ grow,               // BWD: (P*N) d loss / d out[r]
+    float* __restrict__ out,                      // (P*N) sum_g log p
+    float* __restrict__ dlogc_part,               // BWD: (N*PS, G) partial d loss / d log_c
+    int P, int N, int G, int PS) {
+  __shared__ float2 red[6][NT / 64];
+  const int n = blockIdx.x;
+  const int ps = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int G4 = G >> 2;
+
+  // ---- per-cell, per-gene state in registers
+  float4 x[VPT], c[VPT], dmain[VPT];  // dmain: sum_r grow[r] * d log p / dc
+  float lg_local = 0.f;
+  float gsum = 0.f;  // sum of this block's upstream row gradients (scales the digamma part)
+  if (BWD)
+    for (int p = ps; p < P; p += PS) gsum += grow[(int64_t)p * N + n];
+  const float4* X4 = reinterpret_cast<const float4*>(X + (int64_t)n * ldx);
+  const float4* C4 = reinterpret_cast<const float4*>(gene_consts);
+  const float4* LGC4 = reinterpret_cast<const float4*>(gene_consts + G);
+  const float4* PSC4 = reinterpret_cast<const float4*>(gene_consts + 2 * (int64_t)G);
+  const float libn = lib[n];
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int k = j * NT + tid;
+    if (k < G4) {
+      x[j] = X4[k];
+      c[j] = C4[k];
+      const float4 lgc = LGC4[k];
+      float4 dpsi = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BWD) {
+        const float4 psc = PSC4[k];
+        lg_local += nb_lgamma_term<true>(x[j].x, c[j].x, lgc.x, psc.x, dpsi.x);
+        lg_local += nb_lgamma_term<true>(x[j].y, c[j].y, lgc.y, psc.y, dpsi.y);
+        lg_local += nb_lgamma_term<true>(x[j].z, c[j].z, lgc.z, psc.z, dpsi.z);
+        lg_local += nb_lgamma_term<true>(x[j].w, c[j].w, lgc.w, psc.w, dpsi.w);
+      } else {
+        float dummy;
+        lg_local += nb_lgamma_term<false>(x[j].x, c[j].x, lgc.x, 0.f, dummy);
+        lg_local += nb_lgamma_term<false>(x[j].y, c[j].y, lgc.y, 0.f, dummy);
+        lg_local += nb_lgamma_term<false>(x[j].z, c[j].z, lgc.z, 0.f, dummy);
+        lg_local += nb_lgamma_term<false>(x[j].w, c[j].w, lgc.w, 0.f, dummy);
+      }
+      dmain[j] = make_float4(gsum * dpsi.x, gsum * dpsi.y, gsum * dpsi.z, gsum * dpsi.w);
+    } else {
+      x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      c[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+      dmain[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float LG = block_sum<NT>(lg_local, reinterpret_cast<float*>(red[5]));
+
+  // ---- walk this block's particle rows, prefetching one row ahead
+  float4 cur[VPT], nxt[VPT];
+  auto load_row = [&](int p, float4* dst) {
+    const float4* L4 = reinterpret_cast<const float4*>(logits + ((int64_t)p * N + n) * ld_logits);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int k = j * NT + tid;
+      dst[j] = (k < G4) ? L4[k] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+  };
+  if (ps < P) load_row(ps, nxt);
+  int it = 0;
+  for (int p = ps; p < P; p += PS, ++it) {
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) cur[j] = nxt[j];
+    if (p + PS < P) load_row(p + PS, nxt);
+    float2* slot = red[(it & 1) * 3];
+
+    // row max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) mx = fmaxf(fmaxf(fmaxf(cur[j].x, cur[j].y), fmaxf(cur[j].z, cur[j].w)), mx);
+    mx = block_max<NT>(mx, reinterpret_cast<float*>(slot));
+    // exp and row sum
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      cur[j].x = __expf(cur[j].x - mx);
+      cur[j].y = __expf(cur[j].y - mx);
+      cur[j].z = __expf(cur[j].z - mx);
+      cur[j].w = __expf(cur[j].w - mx);
+      se += (cur[j].x + cur[j].y) + (cur[j].z + cur[j].w);
+    }
+    se = block_sum<NT>(se, reinterpret_cast<float*>(slot + 1));
+    const float inv_se = 1.0f / se;
+    const float mu_scale = libn * inv_se;  // mu = e * lib / sum(e)
+
+    const int64_t r = (int64_t)p * N + n;
+    const float g_r = BWD ? grow[r] : 0.f;
+    float tsum = 0.f, usum = 0.f;
+    float4 u[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int k = j * NT + tid;
+      if (k < G4) {
+        float du;
+        tsum += nb_main_term<BWD>(cur[j].x * mu_scale, x[j].x, c[j].x, u[j].x, du);
+        if (BWD) dmain[j].x = fmaf(g_r, du, dmain[j].x);
+        tsum += nb_main_term<BWD>(cur[j].y * mu_scale, x[j].y, c[j].y, u[j].y, du);
+        if (BWD) dmain[j].y = fmaf(g_r, du, dmain[j].y);
+        tsum += nb_main_term<BWD>(cur[j].z * mu_scale, x[j].z, c[j].z, u[j].z, du);
+        if (BWD) dmain[j].z = fmaf(g_r, du, dmain[j].z);
+        tsum += nb_main_term<BWD>(cur[j].w * mu_scale, x[j].w, c[j].w, u[j].w, du);
+        if (BWD) dmain[j].w = fmaf(g_r, du, dmain[j].w);
+        if (BWD) usum += (u[j].x + u[j].y) + (u[j].z + u[j].w);
+      }
+    }
+    const float2 tu = block_sum2<NT>(tsum, usum, slot + 2);
+    if (tid == 0) out[r] = tu.x + LG;
+    if (BWD) {
+      const float U = tu.y;
+      float4* DL4 = reinterpret_cast<float4*>(dlogits + r * ld_dlogits);
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        const int k = j * NT + tid;
+        if (k < G4) {
+          float4 d;
+          d.x = g_r * fmaf(-cur[j].x * inv_se, U, u[j].x);
+          d.y = g_r * fmaf(-cur[j].y * inv_se, U, u[j].y);
+          d.z = g_r * fmaf(-cur[j].z * inv_se, U, u[j].z);
+          d.w = g_r * fmaf(-cur[j].w * inv_se, U, u[j].w);
+          DL4[k] = d;
+        }
+      }
+    }
+  }
+
+  if (BWD) {
+    float4* DP4 = reinterpret_cast<float4*>(dlogc_part + ((int64_t)n * PS + ps) * G);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int k = j * NT + tid;
+      if (k < G4) {
+        float4 d;  // chain through c = exp(log_c)
+        d.x = c[j].x * dmain[j].x;
+        d.y = c[j].y * dmain[j].y;
+        d.z = c[j].z * dmain[j].z;
+        d.w = c[j].w * dmain[j].w;
+        DP4[k] = d;
+      }
+    }
+  }
+}
+
+// Per-gene constants from log_concentration: c = exp(log_c), lgamma(c), digamma(c).
+// (mlp.py:160 `concentration = torch.exp(self.log_concentration)`.)  G threads, evaluated in
+// double so the fp32 constants are correctly rounded.
+__global__ void nb_gene_consts_kernel(const float* __restrict__ log_c, float* __restrict__ gc, int G) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const float cf = expf(log_c[g]);
+  double c = (double)cf;
+  // digamma by recurrence to y >= 10 then the asymptotic series
+  double y = c, ps = 0.0;
+  while (y < 10.0) {
+    ps -= 1.0 / y;
+    y += 1.0;
+  }
+  const double iy = 1.0 / y, iy2 = iy * iy;
+  ps += log(y) - 0.5 * iy - iy2 * (1.0 / 12 - iy2 * (1.0 / 120 - iy2 * (1.0 / 252 - iy2 * (1.0 / 240))));
+  gc[g] = cf;
+  gc[G + g] = (float)lgamma(c);
+  gc[2 * (int64_t)G + g] = (float)ps;
+}
+
+// Deterministic column sum of the (rows, G) partials written by nb_rows_kernel.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int rows, int G,
+                                                      float* __restrict__ out, int accumulate) {
+  // block (64 columns x 4 row-groups); each thread walks rows rg, rg+4, ...
+  __shared__ float sm[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (col < G)
+    for (int r = rg; r < rows; r += 4) acc += part[(int64_t)r * G + col];
+  sm[rg][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rg == 0 && col < G) {
+    const float t = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    out[col] = accumulate ? out[col] + t : t;
+  }
+}
+
+constexpr int kNbMaxGenes = 1024 * 4 * 4;
+
+template <bool BWD>
+static int launch_nb_rows(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
+                          const float* X, int64_t ldx, const float* lib, const float* gene_consts,
+                          const float* grow, float* out, float* dlogc_part, int P, int N, int G, int PS,
+                          hipStream_t stream) {
+  const int G4 = G / 4;
+  dim3 grid(N, PS);
+#define CRADLE_NB_LAUNCH(VPT, NT)                                                                       \
+  hipLaunchKernelGGL((nb_rows_kernel<VPT, NT, BWD>), grid, dim3(NT), 0, stream, logits, ld_logits,      \
+                     dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, dlogc_part, P, N, G, PS)
+  if (G4 <= 256 * 1) CRADLE_NB_LAUNCH(1, 256);
+  else if (G4 <= 256 * 2) CRADLE_NB_LAUNCH(2, 256);
+  else if (G4 <= 256 * 3) CRADLE_NB_LAUNCH(3, 256);
+  else if (G4 <= 256 * 4) CRADLE_NB_LAUNCH(4, 256);
+  else if (G4 <= 256 * 5) CRADLE_NB_LAUNCH(5, 256);
+  else if (G4 <= 512 * 3) CRADLE_NB_LAUNCH(3, 512);
+  else if (G4 <= 512 * 4) CRADLE_NB_LAUNCH(4, 512);
+  else if (G4 <= 1024 * 3) CRADLE_NB_LAUNCH(3, 1024);
+  else if (G4 <= 1024 * 4) CRADLE_NB_LAUNCH(4, 1024);
+  else {
+    cradle_set_error("nb_rows: n_genes=%d exceeds the supported maximum %d", G, kNbMaxGenes);
+    return CRADLE_ERR_UNSUPPORTED;
+  }
+#undef CRADLE_NB_LAUNCH
+  CRADLE_CHECK_LAUNCH("nb_rows_kernel");
+  return CRADLE_OK;
+}
+
+static int check_common(const void* logits, const void* X, const void* lib, const void* gc, const void* out,
+                        int P, int N, int G, int64_t ld_logits, int64_t ldx) {
+  CRADLE_CHECK_ARG(logits && X && lib && gc && out, "nb_logprob: null pointer argument");
+  CRADLE_CHECK_ARG(P > 0 && N > 0 && G > 0, "nb_logprob: P=%d N=%d G=%d must be positive", P, N, G);
+  CRADLE_CHECK_ARG(G % 4 == 0, "nb_logprob: n_genes=%d must be a multiple of 4 (pad the gene axis)", G);
+  CRADLE_CHECK_ARG(ld_logits >= G && ld_logits % 4 == 0 && ldx >= G && ldx % 4 == 0,
+                   "nb_logprob: leading dimensions (%lld, %lld) must be >= G and multiples of 4",
+                   (long long)ld_logits, (long long)ldx);
+  CRADLE_CHECK_ARG(((uintptr_t)logits % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)gc % 16 == 0),
+                   "nb_logprob: logits, X and gene_consts must be 16-byte aligned");
+  return CRADLE_OK;
+}
+
+}  // namespace cradle
+
+using namespace cradle;
+
+extern "C" {
+
+int cradle_nb_gene_consts(const float* log_c, float* gene_consts, int G, hipStream_t stream) {
+  CRADLE_CHECK_ARG(log_c && gene_consts && G > 0, "nb_gene_consts: bad arguments");
+  hipLaunchKernelGGL(nb_gene_consts_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, log_c, gene_consts, G);
+  CRADLE_CHECK_LAUNCH("nb_gene_consts_kernel");
+  return CRADLE_OK;
+}
+
+int cradle_nb_particle_split(int P, int N) {
+  // enough workgroups to cover the chip (256 CUs x 2) without splitting a cell's particles
+  // more than needed: each split re-reads X[n] and redoes the per-cell lgamma terms
+  int ps = 1;
+  while ((int64_t)N * ps < 512 && ps * 2 <= P) ps *= 2;
+  return ps;
+}
+
+int cradle_nb_logprob_fwd(const float* logits, int64_t ld_logits, const float* X, int64_t ldx, const float* lib,
+                          const float* gene_consts, float* out, int P, int N, int G, hipStream_t stream) {
+  int rc = check_common(logits, X, lib, gene_consts, out, P, N, G, ld_logits, ldx);
+  if (rc) return rc;
+  const int PS = cradle_nb_particle_split(P, N);
+  return launch_nb_rows<false>(logits, ld_logits, nullptr, 0, X, ldx, lib, gene_consts, nullptr, out, nullptr, P,
+                               N, G, PS, stream);
+}
+
+int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
+                              const float* X, int64_t ldx, const float* lib, const float* gene_consts,
+                              const float* grow, float* out, float* dlog_c, int accumulate_dlog_c,
+                              float* workspace, int64_t workspace_floats, int P, int N, int G,
+                              hipStream_t stream) {
+  int rc = check_common(logits, X, lib, gene_consts, out, P, N, G, ld_logits, ldx);
+  if (rc) return rc;
+  CRADLE_CHECK_ARG(dlogits && grow && dlog_c && workspace, "nb_logprob_fwd_bwd: null pointer argument");
+  CRADLE_CHECK_ARG(ld_dlogits >= G && ld_dlogits % 4 == 0 && (uintptr_t)dlogits % 16 == 0,
+                   "nb_logprob_fwd_bwd: dlogits must be 16-byte aligned with ld >= G, ld %% 4 == 0");
+  const int PS = cradle_nb_particle_split(P, N);
+  CRADLE_CHECK_ARG(workspace_floats >= (int64_t)N * PS * G && (uintptr_t)workspace % 16 == 0,
+                   "nb_logprob_fwd_bwd: workspace needs %lld floats, 16-byte aligned (got %lld)",
+                   (long long)((int64_t)N * PS * G), (long long)workspace_floats);
+  rc = launch_nb_rows<true>(logits, ld_logits, dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, workspace,
+                            P, N, G, PS, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_kernel, dim3((G + 63) / 64), dim3(256), 0, stream, workspace, N * PS, G, dlog_c,
+                     accumulate_dlog_c);
+  CRADLE_CHECK_LAUNCH("colsum_kernel");
+  return CRADLE_OK;
+}
+
+int64_t cradle_nb_workspace_floats(int P, int N, int G) {
+  return (int64_t)N * cradle_nb_particle_split(P, N) * G;
+}
+
+}  // extern "C"

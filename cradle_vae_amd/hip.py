@@ -1,0 +1,82 @@
+"""ctypes binding of ``csrc/libcradle_hip.so`` (the C ABI declared in ``include/cradle_hip.h``).
+
+There is no CPU or PyTorch fallback: if the library is missing, or a tensor handed to a
+kernel wrapper is not a contiguous fp32 CUDA(HIP) tensor, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libcradle_hip.so")
+_lib: Optional[ctypes.CDLL] = None
+
+c_float_p = ctypes.c_void_p
+c_stream = ctypes.c_void_p
+i32, i64 = ctypes.c_int, ctypes.c_int64
+
+# name -> (restype, argtypes); must list every symbol include/cradle_hip.h declares
+PROTOTYPES = {
+    "cradle_last_error": (ctypes.c_char_p, []),
+    "cradle_abi_version": (i32, []),
+    "cradle_device_count": (i32, []),
+    "cradle_nb_gene_consts": (i32, [c_float_p, c_float_p, i32, c_stream]),
+    "cradle_nb_logprob_fwd": (i32, [c_float_p, i64, c_float_p, i64, c_float_p, c_float_p, c_float_p, i32, i32, i32, c_stream]),
+    "cradle_nb_logprob_fwd_bwd": (
+        i32,
+        [c_float_p, i64, c_float_p, i64, c_float_p, i64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, i32,
+         c_float_p, i64, i32, i32, i32, c_stream],
+    ),
+    "cradle_nb_workspace_floats": (i64, [i32, i32, i32]),
+    "cradle_nb_particle_split": (i32, [i32, i32]),
+}
+
+
+class CradleHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Loads the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise CradleHipError(
+            f"{_LIB_PATH} is missing: build it with `make -C cradle_vae_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path."
+        )
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise CradleHipError(f"{what} failed (code {rc}): {load().cradle_last_error().decode()}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CradleHipError("cradle_vae_amd kernels only run on the GPU; got a CPU tensor (no fallback path)")
+    if t.dtype != torch.float32 and t.dtype != torch.int32:
+        raise CradleHipError(f"expected an fp32/int32 tensor, got {t.dtype}")
+    if not t.is_contiguous():
+        raise CradleHipError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,32 @@
+"""CPU: the C-ABI library loads and exports every symbol include/cradle_hip.h declares."""
+import os
+import re
+
+from cradle_vae_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cradle_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cradle_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = hip.load()
+    names = _declared_symbols()
+    assert len(names) >= 8
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/cradle_hip.h but not exported"
+        assert name in hip.PROTOTYPES, f"{name} has no ctypes prototype in cradle_vae_amd/hip.py"
+    for name in hip.PROTOTYPES:
+        assert name in names, f"{name} bound in hip.py but not declared in the header"
+    assert lib.cradle_abi_version() == 1
+
+
+def test_host_side_helpers_need_no_gpu():
+    lib = hip.load()
+    assert lib.cradle_nb_particle_split(5, 512) == 1
+    assert lib.cradle_nb_particle_split(100, 128) == 4
+    assert lib.cradle_nb_workspace_floats(5, 512, 5000) == 512 * 5000
