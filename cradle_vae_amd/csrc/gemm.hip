@@ -1,0 +1,379 @@
+// K6: fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, an fmaf
+// chain per output element) with the MLP epilogues fused in.
+//
+// Replaces every torch.nn.Linear on the hot path (reference cradle_vae/models/utils/mlp.py:
+// 76-80, 111-119 trunk layers with LeakyReLU + residual, :129-131 Gaussian heads, :153-154
+// decoder output layer) and, for the backward pass, autograd's mm kernels.
+//
+// One kernel template, three operand layouts (no transposed copies are ever made):
+//   NT  C[M,N] = A[M,K] . B[N,K]^T      forward of y = x W^T          (x rows, W rows: K contiguous)
+//   NN  C[M,N] = A[M,K] . B[K,N]        dgrad   dx = dy W             (W rows: N contiguous)
+//   TN  C[M,N] = A[K,M]^T . B[K,N]      wgrad   dW = dy^T x           (both: K is the row index)
+// Tiles are staged global -> registers -> LDS (double buffered, one barrier per K step) in
+// the layout they have in memory: "K-major" tiles [row][k] are read back with one
+// ds_read_b128 per 4 k-values, "MN-major" tiles [k][row] with four ds_read_b32.  The k
+// order inside a step is permuted identically for A and B, which a dot product allows.
+// 256 threads = 4 waves in a 2x2 arrangement; each wave owns TM x TN tiles of 32x32.
+#include "common.h"
+
+namespace cradle {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int KPAD = 4;  // K-major LDS row stride 20 floats: conflict-free ds_read_b128
+
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  float beta;  // C = v + beta * C_old
+  // epilogue (all optional)
+  const float* bias;      // [N]
+  const float* rowbias;   // rowbias[rb_row * ld_rb + col], rb_row = row / rb_n (mode 1) or row % rb_n (mode 2)
+  int64_t ld_rb;
+  int rb_mode, rb_n;
+  const float* rowscale;  // multiplies the rowbias term, indexed by row % rs_n
+  int rs_n;
+  int act;                // 1: LeakyReLU(0.01)
+  float* act_out;         // store of the activation before the residual is added
+  int64_t ld_act;
+  const float* res;       // residual added after the activation
+  int64_t ld_res;
+  const float* dact_src;  // second output C2 = v * (dact_src > 0 ? 1 : 0.01)
+  int64_t ld_ds;
+  float* C2;
+  int64_t ldc2;
+  float* extra_col;       // TN only: B gets a virtual all-ones column N; its result goes here [M]
+  // split-K
+  int splitk;             // grid.z; >1: raw partial tiles to `partial` (z, M, Np), no epilogue
+  float* partial;
+  int k_tiles_per_split;
+};
+
+template <bool KMAJOR, int ROWS>
+struct TileLoader {
+  // One operand tile of ROWS x BK floats per K step; every thread moves ROWS*BK/256/4 float4.
+  static constexpr int NV = ROWS * BK / 4 / 256;
+  float4 regs[NV];
+
+  // row0: first tile row (M or N index), k0: first k.  rows/kdim: logical extents.
+  // ones_row: (MN-major only) logical row index whose value is 1 for every k < kdim, or -1.
+  template <bool VEC>
+  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int k0, int rows,
+                                       int kdim, int ones_row) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KMAJOR) {
+        const int r = row0 + idx / (BK / 4);
+        const int k = k0 + (idx % (BK / 4)) * 4;
+        if (r < rows) {
+          const float* p = P + (int64_t)r * ld + k;
+          if (VEC && k + 3 < kdim) {
+            val = *reinterpret_cast<const float4*>(p);
+          } else {
+            if (k < kdim) val.x = p[0];
+            if (k + 1 < kdim) val.y = p[1];
+            if (k + 2 < kdim) val.z = p[2];
+            if (k + 3 < kdim) val.w = p[3];
+          }
+        }
+      } else {
+        const int k = k0 + idx / (ROWS / 4);
+        const int r = row0 + (idx % (ROWS / 4)) * 4;
+        if (k < kdim) {
+          const float* p = P + (int64_t)k * ld + r;
+          if (VEC && r + 3 < rows) {
+            val = *reinterpret_cast<const float4*>(p);
+          } else {
+            if (r < rows) val.x = p[0];
+            if (r + 1 < rows) val.y = p[1];
+            if (r + 2 < rows) val.z = p[2];
+            if (r + 3 < rows) val.w = p[3];
+          }
+          if (ones_row >= 0) {  // virtual column (index == rows): never read from memory
+            if (r == ones_row) val.x = 1.f;
+            if (r + 1 == ones_row) val.y = 1.f;
+            if (r + 2 == ones_row) val.z = 1.f;
+            if (r + 3 == ones_row) val.w = 1.f;
+          }
+        }
+      }
+      regs[v] = val;
+    }
+  }
+
+  __device__ __forceinline__ void store(float* lds) const {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      if (KMAJOR) {
+        const int r = idx / (BK / 4), k4 = idx % (BK / 4);
+        *reinterpret_cast<float4*>(lds + r * (BK + KPAD) + k4 * 4) = regs[v];
+      } else {
+        const int k = idx / (ROWS / 4), r4 = idx % (ROWS / 4);
+        *reinterpret_cast<float4*>(lds + k * ROWS + r4 * 4) = regs[v];
+      }
+    }
+  }
+  static constexpr int lds_floats() { return KMAJOR ? ROWS * (BK + KPAD) : BK * ROWS; }
+
+  // fragment of 4 k-values (k = ks*8 + 4*h + t, t = 0..3) of tile row `r`
+  __device__ static __forceinline__ float4 frag(const float* lds, int r, int ks, int h) {
+    if (KMAJOR) {
+      return *reinterpret_cast<const float4*>(lds + r * (BK + KPAD) + ks * 8 + 4 * h);
+    } else {
+      const float* p = lds + (ks * 8 + 4 * h) * ROWS + r;
+      return make_float4(p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]);
+    }
+  }
+};
+
+__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : kLeakySlope * v; }
+
+template <bool A_KMAJOR, bool B_KMAJOR, int TM, int TN, bool VEC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+  using LA = TileLoader<A_KMAJOR, BM>;
+  using LB = TileLoader<B_KMAJOR, BN>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (LA::lds_floats() + LB::lds_floats())];
+  constexpr int STAGE = LA::lds_floats() + LB::lds_floats();
+  auto As = [&](int buf) { return lds + buf * STAGE; };
+  auto Bs = [&](int buf) { return lds + buf * STAGE + LA::lds_floats(); };
+
+  // XCD-aware tile order: consecutive workgroups land on different XCDs, so give each XCD a
+  // contiguous run of tiles (neighbouring tiles share an A row panel in its L2).
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int Np = p.N + (p.extra_col ? 1 : 0);
+  const int tiles_n = (Np + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, pos = wg / 8;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  const int tile_m = wg / tiles_n, tile_n = wg % tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int k_tiles = (p.K + BK - 1) / BK;
+  int kt_begin = 0, kt_end = k_tiles;
+  if (p.splitk > 1) {
+    kt_begin = blockIdx.z * p.k_tiles_per_split;
+    kt_end = min(k_tiles, kt_begin + p.k_tiles_per_split);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  LA la;
+  LB lb;
+  const int ones_row = p.extra_col ? p.N : -1;
+  if (kt_begin < kt_end) {
+    la.template load<VEC>(p.A, p.lda, row0, kt_begin * BK, p.M, p.K, -1);
+    lb.template load<VEC>(p.B, p.ldb, col0, kt_begin * BK, p.N, p.K, B_KMAJOR ? -1 : ones_row);
+    la.store(As(0));
+    lb.store(Bs(0));
+  }
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) {
+      la.template load<VEC>(p.A, p.lda, row0, (kt + 1) * BK, p.M, p.K, -1);
+      lb.template load<VEC>(p.B, p.ldb, col0, (kt + 1) * BK, p.N, p.K, B_KMAJOR ? -1 : ones_row);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 8; ++ks) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = LA::frag(As(cur), (wm * TM + i) * 32 + li, ks, lh);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = LB::frag(Bs(cur), (wn * TN + j) * 32 + li, ks, lh);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < kt_end) {
+      la.store(As(cur ^ 1));
+      lb.store(Bs(cur ^ 1));
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc element e of lane: row = (e&3) + 8*(e>>2) + 4*lh, col = li
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = col0 + (wn * TN + j) * 32 + li;
+      if (col >= Np) continue;
+      const float bias = (p.splitk <= 1 && p.bias && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = row0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (row >= p.M) continue;
+        float v = acc[i][j][e];
+        if (p.splitk > 1) {
+          p.partial[((int64_t)blockIdx.z * p.M + row) * Np + col] = v;
+          continue;
+        }
+        if (col == p.N) {  // virtual ones column -> bias gradient
+          p.extra_col[row] = v + (p.beta != 0.f ? p.beta * p.extra_col[row] : 0.f);
+          continue;
+        }
+        v += bias;
+        if (p.rowbias) {
+          const int rb_row = p.rb_mode == 1 ? row / p.rb_n : row % p.rb_n;
+          const float rb = p.rowbias[(int64_t)rb_row * p.ld_rb + col];
+          v += p.rowscale ? p.rowscale[row % p.rs_n] * rb : rb;
+        }
+        if (p.act) v = leaky(v);
+        if (p.act_out) p.act_out[(int64_t)row * p.ld_act + col] = v;
+        if (p.res) v += p.res[(int64_t)row * p.ld_res + col];
+        if (p.beta != 0.f) v += p.beta * p.C[(int64_t)row * p.ldc + col];
+        p.C[(int64_t)row * p.ldc + col] = v;
+        if (p.C2) p.C2[(int64_t)row * p.ldc2 + col] = v * (p.dact_src[(int64_t)row * p.ld_ds + col] > 0.f ? 1.f : kLeakySlope);
+      }
+    }
+}
+
+// Sums the split-K partial tiles and applies beta / the ones-column output.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splitk, int M, int N,
+                                                            int Np, float* __restrict__ C, int64_t ldc, float beta,
+                                                            float* __restrict__ extra_col) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * Np) return;
+  const int row = idx / Np, col = idx % Np;
+  float v = 0.f;
+  for (int z = 0; z < splitk; ++z) v += partial[((int64_t)z * M + row) * Np + col];
+  if (col == N) {
+    extra_col[row] = v + (beta != 0.f ? beta * extra_col[row] : 0.f);
+  } else {
+    float* c = C + (int64_t)row * ldc + col;
+    *c = v + (beta != 0.f ? beta * *c : 0.f);
+  }
+}
+
+template <bool AK, bool BKM>
+static void launch_cfg(const GemmParams& p, int tm, int tn, bool vec, dim3 grid, hipStream_t s) {
+#define CRADLE_GEMM_CASE(TM_, TN_)                                                                      \
+  if (tm == TM_ && tn == TN_) {                                                                        \
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, true>), grid, dim3(256), 0, s, p); \
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, false>), grid, dim3(256), 0, s, p);    \
+    return;                                                                                            \
+  }
+  CRADLE_GEMM_CASE(2, 2)
+  CRADLE_GEMM_CASE(1, 2)
+  CRADLE_GEMM_CASE(1, 1)
+#undef CRADLE_GEMM_CASE
+}
+
+int64_t gemm_workspace_floats(int layout, int M, int N, int K, int extra_col) {
+  (void)layout;
+  // worst case split factor 32
+  return (int64_t)32 * M * (N + (extra_col ? 1 : 0));
+}
+
+// Host-side dispatch.  workspace is only needed when the problem is split along K.
+int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_floats, hipStream_t stream) {
+  CRADLE_CHECK_ARG(layout >= 0 && layout <= 2, "gemm: bad layout %d", layout);
+  CRADLE_CHECK_ARG(p.A && p.B && p.C && p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad arguments M=%d N=%d K=%d", p.M, p.N, p.K);
+  CRADLE_CHECK_ARG(!p.extra_col || layout == 2, "gemm: the ones-column output needs the TN layout");
+  const int Np = p.N + (p.extra_col ? 1 : 0);
+  // tile choice: the largest tile that still gives every CU a workgroup
+  int tm = 2, tn = 2;
+  auto tiles = [&](int tm_, int tn_) { return (int64_t)((p.M + 64 * tm_ - 1) / (64 * tm_)) * ((Np + 64 * tn_ - 1) / (64 * tn_)); };
+  if (tiles(2, 2) < 256) { tm = 1; tn = 2; }
+  if (tm == 1 && tiles(1, 2) < 256) { tm = 1; tn = 1; }
+  const int64_t ntiles = tiles(tm, tn);
+  const int k_tiles = (p.K + BK - 1) / BK;
+  int splitk = 1;
+  const bool plain = !p.bias && !p.rowbias && !p.act && !p.act_out && !p.res && !p.C2;
+  if (plain && workspace && ntiles < 192 && k_tiles >= 16) {
+    splitk = (int)min((int64_t)32, (384 + ntiles - 1) / ntiles);
+    splitk = min(splitk, k_tiles / 8);
+    while (splitk > 1 && (int64_t)splitk * p.M * Np > workspace_floats) --splitk;
+    if (splitk < 1) splitk = 1;
+  }
+  p.splitk = splitk;
+  p.partial = workspace;
+  p.k_tiles_per_split = (k_tiles + splitk - 1) / splitk;
+  if (splitk > 1) p.splitk = splitk = (k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
+  const bool aligned = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.B % 16 == 0) && p.lda % 4 == 0 && p.ldb % 4 == 0;
+  dim3 grid((unsigned)ntiles, 1, (unsigned)splitk);
+  if (layout == 0) launch_cfg<true, true>(p, tm, tn, aligned, grid, stream);
+  else if (layout == 1) launch_cfg<true, false>(p, tm, tn, aligned, grid, stream);
+  else launch_cfg<false, false>(p, tm, tn, aligned, grid, stream);
+  CRADLE_CHECK_LAUNCH("gemm_f32_kernel");
+  if (splitk > 1) {
+    const int64_t total = (int64_t)p.M * Np;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, workspace,
+                       splitk, p.M, p.N, Np, p.C, p.ldc, p.beta, p.extra_col);
+    CRADLE_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
+  return CRADLE_OK;
+}
+
+}  // namespace cradle
+
+using namespace cradle;
+
+extern "C" {
+
+// Public descriptor (include/cradle_hip.h: cradle_gemm_desc).  Field order is ABI.
+struct cradle_gemm_desc {
+  int layout, M, N, K;
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  float beta;
+  int act;
+  const float* bias;
+  const float* rowbias; int64_t ld_rowbias; int rowbias_mode, rowbias_n;
+  const float* rowscale; int rowscale_n;
+  float* act_out; int64_t ld_act_out;
+  const float* residual; int64_t ld_residual;
+  const float* dact_src; int64_t ld_dact_src;
+  float* C2; int64_t ldc2;
+  float* extra_col;
+};
+
+int cradle_gemm_f32(const cradle_gemm_desc* d, float* workspace, int64_t workspace_floats, hipStream_t stream) {
+  CRADLE_CHECK_ARG(d, "gemm: null descriptor");
+  GemmParams p = {};
+  p.A = d->A; p.B = d->B; p.C = d->C; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.beta = d->beta;
+  p.bias = d->bias; p.rowbias = d->rowbias; p.ld_rb = d->ld_rowbias; p.rb_mode = d->rowbias_mode; p.rb_n = d->rowbias_n;
+  p.rowscale = d->rowscale; p.rs_n = d->rowscale_n;
+  p.act = d->act; p.act_out = d->act_out; p.ld_act = d->ld_act_out;
+  p.res = d->residual; p.ld_res = d->ld_residual; p.dact_src = d->dact_src; p.ld_ds = d->ld_dact_src;
+  p.C2 = d->C2; p.ldc2 = d->ldc2; p.extra_col = d->extra_col;
+  CRADLE_CHECK_ARG(!p.C2 || p.dact_src, "gemm: C2 needs dact_src");
+  CRADLE_CHECK_ARG(!p.rowbias || ((p.rb_mode == 1 || p.rb_mode == 2) && p.rb_n > 0), "gemm: bad rowbias mode");
+  CRADLE_CHECK_ARG(!p.rowscale || (p.rowbias && p.rs_n > 0), "gemm: rowscale needs rowbias");
+  return gemm_f32(d->layout, p, workspace, workspace_floats, stream);
+}
+
+int64_t cradle_gemm_workspace_floats(int layout, int M, int N, int K, int extra_col) {
+  return gemm_workspace_floats(layout, M, N, K, extra_col);
+}
+
+}  // extern "C"

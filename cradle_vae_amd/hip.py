@@ -32,7 +32,30 @@ PROTOTYPES = {
     ),
     "cradle_nb_workspace_floats": (i64, [i32, i32, i32]),
     "cradle_nb_particle_split": (i32, [i32, i32]),
+    "cradle_gemm_f32": (i32, [ctypes.c_void_p, c_float_p, i64, c_stream]),
+    "cradle_gemm_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
 }
+
+
+class GemmDesc(ctypes.Structure):
+    """struct cradle_gemm_desc (include/cradle_hip.h); field order is ABI."""
+
+    _fields_ = [
+        ("layout", i32), ("M", i32), ("N", i32), ("K", i32),
+        ("A", ctypes.c_void_p), ("lda", i64),
+        ("B", ctypes.c_void_p), ("ldb", i64),
+        ("C", ctypes.c_void_p), ("ldc", i64),
+        ("beta", ctypes.c_float),
+        ("act", i32),
+        ("bias", ctypes.c_void_p),
+        ("rowbias", ctypes.c_void_p), ("ld_rowbias", i64), ("rowbias_mode", i32), ("rowbias_n", i32),
+        ("rowscale", ctypes.c_void_p), ("rowscale_n", i32),
+        ("act_out", ctypes.c_void_p), ("ld_act_out", i64),
+        ("residual", ctypes.c_void_p), ("ld_residual", i64),
+        ("dact_src", ctypes.c_void_p), ("ld_dact_src", i64),
+        ("C2", ctypes.c_void_p), ("ldc2", i64),
+        ("extra_col", ctypes.c_void_p),
+    ]
 
 
 class CradleHipError(RuntimeError):

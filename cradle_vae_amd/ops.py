@@ -66,3 +66,66 @@ def nb_logprob_fwd_bwd(
         "nb_logprob_fwd_bwd",
     )
     return out, dlogits, dlog_c
+
+
+NT, NN, TN = 0, 1, 2
+
+
+def _mat(t: torch.Tensor):
+    """(pointer, leading dimension) of a 2-D fp32 CUDA tensor view whose rows are contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda or t.dtype != torch.float32:
+        raise hip.CradleHipError("gemm operands must be 2-D fp32 CUDA tensors with unit column stride")
+    return t.data_ptr(), t.stride(0)
+
+
+def gemm(
+    layout: int, A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, *, beta: float = 0.0,
+    bias: Optional[torch.Tensor] = None, act: bool = False, act_out: Optional[torch.Tensor] = None,
+    residual: Optional[torch.Tensor] = None, dact_src: Optional[torch.Tensor] = None,
+    out2: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None, rowbias_mode: int = 0,
+    rowbias_n: int = 0, rowscale: Optional[torch.Tensor] = None, extra_col: Optional[torch.Tensor] = None,
+    workspace: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """fp32 MFMA GEMM with the fused epilogue of ``cradle_gemm_f32`` (see the header)."""
+    if layout == NT:
+        (M, K), (N, K2) = A.shape, B.shape
+    elif layout == NN:
+        (M, K), (K2, N) = A.shape, B.shape
+    else:
+        (K, M), (K2, N) = A.shape, B.shape
+    if K != K2:
+        raise hip.CradleHipError(f"gemm: inner dimensions differ ({K} vs {K2})")
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    if out.shape != (M, N):
+        raise hip.CradleHipError(f"gemm: out has shape {tuple(out.shape)}, expected {(M, N)}")
+    d = hip.GemmDesc()
+    d.layout, d.M, d.N, d.K = layout, M, N, K
+    d.A, d.lda = _mat(A)
+    d.B, d.ldb = _mat(B)
+    d.C, d.ldc = _mat(out)
+    d.beta, d.act = beta, int(act)
+    d.bias = hip.ptr(bias)
+    if rowbias is not None:
+        d.rowbias, d.ld_rowbias = _mat(rowbias)
+        d.rowbias_mode, d.rowbias_n = rowbias_mode, rowbias_n
+    if rowscale is not None:
+        d.rowscale, d.rowscale_n = hip.ptr(rowscale), rowscale.numel()
+    for name, t in (("act_out", act_out), ("residual", residual), ("dact_src", dact_src)):
+        if t is not None:
+            if t.shape != (M, N):
+                raise hip.CradleHipError(f"gemm: {name} has shape {tuple(t.shape)}, expected {(M, N)}")
+            ptr_, ld = _mat(t)
+            setattr(d, name, ptr_)
+            setattr(d, "ld_" + name, ld)
+    if out2 is not None:
+        d.C2, d.ldc2 = _mat(out2)
+    if extra_col is not None:
+        if extra_col.numel() != M:
+            raise hip.CradleHipError("gemm: extra_col must have M elements")
+        d.extra_col = hip.ptr(extra_col)
+    ws_ptr, ws_n = (hip.ptr(workspace), workspace.numel()) if workspace is not None else (None, 0)
+    import ctypes
+
+    hip.check(hip.load().cradle_gemm_f32(ctypes.byref(d), ws_ptr, ws_n, hip.stream()), "gemm_f32")
+    return out

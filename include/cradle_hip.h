@@ -72,6 +72,39 @@ int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlo
 int64_t cradle_nb_workspace_floats(int P, int N, int G);
 int cradle_nb_particle_split(int P, int N);
 
+/* ---- K6: fp32 matrix-core GEMM with fused MLP epilogues ---------------------------------
+ * Replaces torch.nn.Linear (+ LeakyReLU + residual) of cradle_vae/models/utils/mlp.py:76-80,
+ * 111-119, 129-131, 153-154 and the mm kernels autograd runs for them in backward.
+ *   layout 0 (NT): C[M,N] = A[M,K] . B[N,K]^T     y  = x W^T
+ *   layout 1 (NN): C[M,N] = A[M,K] . B[K,N]       dx = dy W
+ *   layout 2 (TN): C[M,N] = A[K,M]^T . B[K,N]     dW = dy^T x
+ * v = acc + bias[col] + rowscale[row % rowscale_n] * rowbias[rb_row, col]
+ *       (rb_row = row / rowbias_n if rowbias_mode == 1, row % rowbias_n if 2)
+ * if act: v = LeakyReLU_0.01(v);  act_out = v;  v += residual;  C = v + beta * C;
+ * C2 = v * (dact_src > 0 ? 1 : 0.01)  (LeakyReLU backward of the previous layer);
+ * extra_col (layout 2 only): row sums of A^T, i.e. the bias gradient, as a virtual ones column.
+ * Arithmetic: v_mfma_f32_32x32x2_f32, exact fp32 (one rounding per product). */
+typedef struct cradle_gemm_desc {
+  int layout, M, N, K;
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  float beta;
+  int act;
+  const float* bias;
+  const float* rowbias; int64_t ld_rowbias; int rowbias_mode, rowbias_n;
+  const float* rowscale; int rowscale_n;
+  float* act_out; int64_t ld_act_out;
+  const float* residual; int64_t ld_residual;
+  const float* dact_src; int64_t ld_dact_src;
+  float* C2; int64_t ldc2;
+  float* extra_col;
+} cradle_gemm_desc;
+
+/* workspace (optional, may be NULL): lets small-output / long-K problems split along K. */
+int cradle_gemm_f32(const cradle_gemm_desc* desc, float* workspace, int64_t workspace_floats, cradle_stream_t stream);
+int64_t cradle_gemm_workspace_floats(int layout, int M, int N, int K, int extra_col);
+
 #ifdef __cplusplus
 }
 #endif

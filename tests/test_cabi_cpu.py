@@ -30,3 +30,12 @@ def test_host_side_helpers_need_no_gpu():
     assert lib.cradle_nb_particle_split(5, 512) == 1
     assert lib.cradle_nb_particle_split(100, 128) == 4
     assert lib.cradle_nb_workspace_floats(5, 512, 5000) == 512 * 5000
+
+
+def test_library_is_newer_than_its_sources():
+    """The .so travels to the GPU box prebuilt: a stale build would silently test old code."""
+    import glob
+
+    so = os.path.getmtime(hip.lib_path())
+    for src in glob.glob(os.path.join(ROOT, "cradle_vae_amd", "csrc", "*.h*")):
+        assert os.path.getmtime(src) <= so, f"{src} is newer than libcradle_hip.so: run make -C cradle_vae_amd/csrc"
