@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the CRADLE-VAE ELBO training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--shape norman] [--step-impl auto]
+
+A "step" = one per-minibatch ELBO forward + backward + gradient-norm clip + Adam update
+(reference: PerturbationLightningModule.training_step + Lightning's backward/clip/optimizer,
+cradle_vae/models/utils/perturbation_lightning_module.py:90-107,147-150, train_norman.py:96)
+on one synthetic batch of the Norman shape (demo/cradle_vae_norman.yaml: N=512 cells/GPU,
+P=5 particles, G=5000, T=105, L=200, H=400), inputs resident in HBM.  With N>1 (launched by
+torch.distributed.run, one rank per GPU) every rank steps its own cell shard and gradients
+are averaged with one RCCL all-reduce: weak scaling, value = N_gpus * 512 cells / step time.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the NB-likelihood kernel (K1), timed
+with HIP events on its stream inside the timed region; `cpu_baseline` is the CPU oracle
+(a port of the reference's PyTorch path, oracle/cradle_oracle.py) timed on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def build(shape, device, seed):
+    from cradle_vae_amd import synthetic as syn
+    from cradle_vae_amd.guide import ObservationNormalizationStatistics, cradle_vae_CorrelatedNormalGuide
+    from cradle_vae_amd.loss_module import cradle_vae_ELBOLossModule
+    from cradle_vae_amd.model import cradle_vae_Model
+
+    batch = syn.make_batch(shape, seed=seed, device=device)
+    torch.manual_seed(0)  # identical initial weights on every rank
+    model = cradle_vae_Model(
+        n_latent=shape.n_latent, n_treatments=shape.n_treatments, n_phenos=shape.n_phenos, n_qc=shape.n_qc,
+        mask_prior_prob=shape.mask_prior_prob, embedding_prior_scale=1.0, likelihood_key="library_nb",
+        decoder_n_layers=shape.decoder_n_layers, decoder_n_hidden=shape.decoder_n_hidden, sum_mode=False)
+    stats = ObservationNormalizationStatistics(log_x_mean=batch["log_x_mean"].cpu(), log_x_std=batch["log_x_std"].cpu())
+    guide = cradle_vae_CorrelatedNormalGuide(
+        n_latent=shape.n_latent, n_treatments=shape.n_treatments, n_phenos=shape.n_phenos, n_qc=shape.n_qc,
+        basal_encoder_n_layers=shape.basal_encoder_n_layers, basal_encoder_n_hidden=shape.basal_encoder_n_hidden,
+        basal_encoder_input_normalization="log_standardize",
+        embedding_encoder_n_layers=shape.embedding_encoder_n_layers,
+        embedding_encoder_n_hidden=shape.embedding_encoder_n_hidden, x_normalization_stats=stats)
+    lm = cradle_vae_ELBOLossModule(model=model, guide=guide, beta=shape.beta).to(device)
+    return lm, batch
+
+
+def cpu_baseline(shape, seconds_budget=25.0):
+    """The reference's PyTorch path (CPU oracle restatement, fp32, autograd + Adam), timed on
+    this host's cores on a bounded sample of the same workload."""
+    from cradle_vae_amd import synthetic as syn
+    from oracle import cradle_oracle as co
+
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "64")))))
+    b = syn.make_batch(shape, seed=0)
+    params = co.init_params(
+        n_latent=shape.n_latent, n_treatments=shape.n_treatments, n_phenos=shape.n_phenos, n_qc=shape.n_qc,
+        decoder_n_layers=shape.decoder_n_layers, decoder_n_hidden=shape.decoder_n_hidden,
+        basal_encoder_n_layers=shape.basal_encoder_n_layers, basal_encoder_n_hidden=shape.basal_encoder_n_hidden,
+        embedding_encoder_n_layers=shape.embedding_encoder_n_layers,
+        embedding_encoder_n_hidden=shape.embedding_encoder_n_hidden, mask_prior_prob=shape.mask_prior_prob,
+        log_x_mean=b["log_x_mean"], log_x_std=b["log_x_std"], randomize=False)
+    keys = co.trainable_keys(params)
+    leaves = [params[k].clone().requires_grad_(True) for k in keys]
+    opt = torch.optim.Adam(leaves, lr=3e-4, weight_decay=1e-6)
+    times = []
+    t_start = time.perf_counter()
+    it = 0
+    while True:
+        n1, n2 = syn.make_noise(shape, 100 + it), syn.make_noise(shape, 200 + it)
+        p2 = dict(params)
+        p2.update(dict(zip(keys, leaves)))
+        t0 = time.perf_counter()
+        loss, _, _ = co.elbo_loss(
+            p2, X=b["X"], D=b["D"], qc=b["qc"], cfX=b["cfX"], library_size=b["library_size"],
+            D_obs_counts=b["D_obs_counts"], qc_obs_counts=b["qc_obs_counts"], noise=n1, cf_noise=n2,
+            n_particles=shape.n_particles, beta=shape.beta)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(leaves, 100.0)
+        opt.step()
+        dt = time.perf_counter() - t0
+        if it > 0 or dt > seconds_budget / 2:
+            times.append(dt)
+        it += 1
+        if time.perf_counter() - t_start > seconds_budget or it >= 12:
+            break
+    t = sorted(times)[len(times) // 2]
+    return {
+        "value": shape.n_cells / t,
+        "unit": "cells/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{len(times)} timed ELBO fwd+bwd+Adam steps of the same {shape.name} batch shape "
+                  f"(oracle/cradle_oracle.py, fp32, minimal form without the unused x draws), median {t:.3f} s/step",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shape", default="norman")
+    ap.add_argument("--step-impl", default="auto", choices=["auto", "fused", "modular"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from cradle_vae_amd import hip, ops
+    from cradle_vae_amd import synthetic as syn
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+    hip.load()
+
+    shape = syn.SHAPES[args.shape]
+    lm, batch = build(shape, device, seed=1000 + rank)  # each rank: its own cell shard
+    lm.step = args.step_impl
+    from cradle_vae_amd.trainer import TrainStep
+
+    stepper = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=world)
+
+    def one_step(i):
+        return stepper(batch, n_particles=shape.n_particles)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ops.KERNEL_TIMERS.clear()
+    ops.KERNEL_TIMING = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.KERNEL_TIMING = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms_per_step = elapsed / args.steps * 1e3
+    cells_per_s = shape.n_cells * world / (elapsed / args.steps)
+
+    if rank == 0:
+        # ---- roofline of K1 from the HIP events recorded around its launches in the timed region
+        P, N, G = shape.n_particles, shape.n_cells, shape.n_phenos
+        k1 = [s.elapsed_time(e) * 1e-3 for (name, s, e) in ops.KERNEL_TIMERS if name == "nb_logprob_fwd_bwd"]
+        V = stepper.decoder_variants  # decoder variants scored per cell (2 = as the reference, 1 = live variant only)
+        alg_bytes = 4.0 * G * (3 * P * N + 2 * N)  # SURVEY 8(d) per launch of one variant: fwd+bwd
+        roofline = None
+        if k1:
+            t_k1 = sum(k1) / len(k1)
+            ach = alg_bytes / t_k1 / 1e9
+            roofline = {
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "nb_rows_kernel<BWD> (K1 fused fwd+bwd, one decoder variant per launch)",
+                "launch_us": t_k1 * 1e6, "launches_per_step": len(k1) / args.steps,
+                "algorithmic_bytes_per_launch": alg_bytes,
+            }
+        out = {
+            "metric": "cells/sec ELBO fwd+bwd (Norman shape)",
+            "value": cells_per_s,
+            "unit": "cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{shape.name}: ELBO fwd+bwd+clip+Adam, N={N} cells/GPU, P={P}, G={G}, "
+                            f"T={shape.n_treatments}, L={shape.n_latent}, H={shape.decoder_n_hidden}",
+                "step_impl": stepper.impl, "decoder_variants_per_cell": V, "parallelism": f"dp{world}",
+                "loss": float(loss),
+            },
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(shape)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,185 @@
+"""ELBO loss -- mirror of ``PerturbationPlatedELBOLossModule`` (cradle_vae/models/utils/
+loss_modules.py:8-232) and its subclass ``cradle_vae_ELBOLossModule`` (cradle_vae/models/
+cradle_vae/loss_module.py:12-24).
+
+``loss()`` has two implementations with identical semantics:
+  * ``step='fused'``  (default when available): one call into the C step, which runs the
+    whole forward + backward as hand-written HIP kernels (cradle_vae_amd.step);
+  * ``step='modular'``: composes guide / model like the reference does, every GEMM and the
+    NB likelihood through the HIP kernels with autograd wiring (cradle_vae_amd.functional).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional
+
+import torch
+
+from .distributions import LibraryGammaPoisson
+
+
+class PerturbationPlatedELBOLossModule(torch.nn.Module):
+    def __init__(
+        self,
+        model: torch.nn.Module,
+        guide: torch.nn.Module,
+        local_variables: Optional[Iterable[str]] = None,
+        perturbation_plated_variables: Optional[Iterable[str]] = None,
+        pos_weight: int = None,
+        alpha: int = None,
+        beta: int = 1,
+    ):
+        super().__init__()
+        local_variables = list(local_variables) if local_variables is not None else []
+        perturbation_plated_variables = (
+            list(perturbation_plated_variables) if perturbation_plated_variables is not None else []
+        )
+        assert sorted(model.get_var_keys()) == sorted(guide.get_var_keys()), "Mismatch in model and guide variables"
+        variables = local_variables + perturbation_plated_variables
+        assert sorted(list(model.get_var_keys())) == sorted(
+            variables
+        ), "Mismatch between model variables and variables specified to loss module"
+        self.model = model
+        self.guide = guide
+        self.local_variables = local_variables
+        self.perturbation_plated_variables = perturbation_plated_variables
+        self.pos_weight = pos_weight
+        self.alpha = alpha
+        self.beta = beta
+        self.step = "auto"  # 'auto' | 'fused' | 'modular'
+        self._fused = None
+
+    # ------------------------------------------------------------------ forward (6-tuple)
+    def forward(self, X, D, qc, cfX, condition_values=None, n_particles: int = 1, noise=None, cf_noise=None,
+                sample_x: bool = True):
+        """loss_modules.py:54-106: guide(X, qc) -> model -> guide(cfX, 1 - qc)."""
+        if condition_values is None:
+            condition_values = dict()
+        guide_dists, guide_samples = self.guide(X=X, D=D, qc=qc, n_particles=n_particles, noise=noise)
+        for k, v in guide_samples.items():
+            condition_values[k] = v
+        model_dists, model_samples = self.model(
+            D=D, qc=qc, condition_values=condition_values, n_particles=n_particles, sample_x=sample_x)
+        cf_guide_dists, cf_guide_samples = self.guide(X=cfX, D=D, qc=(1 - qc), n_particles=n_particles, noise=cf_noise)
+        return guide_dists, model_dists, model_samples, cf_guide_dists, cf_guide_samples, None
+
+    # ------------------------------------------------------------------ loss
+    def loss(self, X, D, D_obs_counts, qc, qc_obs_counts, cfX=None, condition_values=None, n_particles: int = 1,
+             test: bool = False, x_var_info=None, noise=None, cf_noise=None):
+        """loss_modules.py:110-187 -> (loss, metrics)."""
+        if self._use_fused(X):
+            return self._fused_step()(
+                X=X, D=D, D_obs_counts=D_obs_counts, qc=qc, qc_obs_counts=qc_obs_counts, cfX=cfX,
+                library_size=condition_values["library_size"], n_particles=n_particles, noise=noise, cf_noise=cf_noise)
+        return self._loss_modular(X, D, D_obs_counts, qc, qc_obs_counts, cfX, condition_values, n_particles,
+                                  noise, cf_noise)
+
+    def _use_fused(self, X) -> bool:
+        if self.step == "modular":
+            return False
+        try:
+            from . import step as step_mod
+        except ImportError:
+            if self.step == "fused":
+                raise
+            return False
+        ok = step_mod.supports(self)
+        if self.step == "fused" and not ok:
+            raise NotImplementedError("this configuration is not supported by the fused HIP step")
+        return ok
+
+    def _fused_step(self):
+        if self._fused is None:
+            from . import step as step_mod
+
+            self._fused = step_mod.FusedElboStep(self)
+        return self._fused
+
+    def _loss_modular(self, X, D, D_obs_counts, qc, qc_obs_counts, cfX, condition_values, n_particles, noise,
+                      cf_noise):
+        guide_dists, model_dists, samples, cf_guide_dists, _, _ = self.forward(
+            X=X, D=D, cfX=cfX, qc=qc, condition_values=condition_values, n_particles=n_particles, noise=noise,
+            cf_noise=cf_noise, sample_x=False)
+        loss_terms = {}
+        good: LibraryGammaPoisson = model_dists["p_x_good"]
+        bad: LibraryGammaPoisson = model_dists["p_x_bad"]
+        alpha = self.alpha
+        if alpha is None:
+            alpha = qc.sum() / qc.shape[0]
+        if qc.shape[1] > 1:
+            qc = qc.max(axis=1)[0].unsqueeze(-1)
+        qrow = qc.squeeze(-1)  # (N,) broadcast over particles
+        # gene sums first, weights after: identical to loss_modules.py:142-143 up to fp reassociation
+        loss_terms["reconstruction"] = alpha * ((1 - qrow) * good.log_prob_sum(X)) + (1 - alpha) * (
+            qrow * bad.log_prob_sum(X))
+
+        idx = torch.nonzero(cfX.sum(1) != 0).squeeze(1)
+        kl_loss = self.beta * self.kldiv_normal(
+            cf_guide_dists["q_z_basal"].mean[:, idx, :], cf_guide_dists["q_z_basal"].stddev[:, idx, :],
+            guide_dists["q_z_cf_basal"].mean[:, idx, :], guide_dists["q_z_cf_basal"].stddev[:, idx, :])
+        kl_loss = kl_loss.sum()
+
+        for k in guide_dists.keys():
+            var_key = k[2:]
+            if k == "q_z_cf_basal":
+                continue
+            loss_term = model_dists[f"p_{var_key}"].log_prob(samples[var_key])
+            loss_term = loss_term - guide_dists[f"q_{var_key}"].log_prob(samples[var_key])
+            if var_key in self.perturbation_plated_variables:
+                if "qc" in var_key:
+                    loss_term = self._compute_reweighted_perturbation_plated_loss_term(qc, qc_obs_counts, loss_term)
+                else:
+                    loss_term = self._compute_reweighted_perturbation_plated_loss_term(D, D_obs_counts, loss_term)
+            loss_terms[var_key] = loss_term.sum(-1)
+
+        batch_elbo = sum(loss_terms.values())
+        loss = -batch_elbo.mean() + kl_loss
+        # one device->host transfer for all metrics instead of the reference's five (:182-184)
+        stacked = torch.stack([-v.detach().mean() for v in loss_terms.values()]).cpu()
+        metrics = {f"loss_term_{k}": stacked[i] for i, k in enumerate(loss_terms)}
+        metrics["cf_KLdivergence"] = kl_loss
+        return loss, metrics
+
+    @staticmethod
+    def kldiv_normal(mu1, sigma1, mu2, sigma2):
+        """loss_modules.py:190-196 (as written there; not the textbook KL)."""
+        logvar1 = 2 * sigma1.log()
+        logvar2 = 2 * sigma2.log()
+        return torch.mean(
+            -0.5 * torch.sum(1.0 + logvar1 - logvar2 - (mu1 - mu2) ** 2 - (logvar1 - logvar2).exp(), dim=1), dim=0)
+
+    @staticmethod
+    def _compute_reweighted_perturbation_plated_loss_term(conditioning_variable, total_obs_per_condition, loss_term):
+        """loss_modules.py:200-232."""
+        condition_nonzero = (conditioning_variable != 0).type(torch.float32)
+        obs_scaling = 1 / total_obs_per_condition
+        obs_scaling = torch.where(torch.isinf(obs_scaling), torch.zeros_like(obs_scaling), obs_scaling).reshape(1, -1)
+        return torch.matmul(condition_nonzero * obs_scaling, loss_term)
+
+
+class cradle_vae_ELBOLossModule(PerturbationPlatedELBOLossModule):
+    def __init__(self, model, guide, pos_weight: int = None, beta: int = 1, alpha: int = None):
+        super().__init__(
+            model=model, guide=guide, local_variables=["z_basal"],
+            perturbation_plated_variables=["E", "mask", "qc_E"], pos_weight=pos_weight, beta=beta, alpha=alpha)
+
+
+class _BrokenInReference(torch.nn.Module):
+    """The reference exports these names (cradle_vae/models/__init__.py:1-8) but their ``loss``
+    cannot run there: IWELBO.loss calls forward without cfX
+    (loss_modules.py:517-523) and CustomReweighted.loss omits qc_obs_counts (:379-385).
+    Kept importable, nothing more."""
+
+    def __init__(self, model, guide, *args, **kwargs):
+        super().__init__()
+        self.model, self.guide = model, guide
+
+    def loss(self, *args, **kwargs):
+        raise NotImplementedError(f"{type(self).__name__}.loss is broken in the reference and not provided here")
+
+
+class cradle_vae_CustomReweightedELBOLossModule(_BrokenInReference):
+    pass
+
+
+class cradle_vae_IWELBOLossModule(_BrokenInReference):
+    pass

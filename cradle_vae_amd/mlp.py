@@ -1,0 +1,106 @@
+"""MLP blocks of the reference (cradle_vae/models/utils/mlp.py) on the HIP GEMM.
+
+Module / parameter names reproduce the reference's state-dict keys
+(``mlp.layers.{i}.0.{weight,bias}``, ``mean_encoder.*``, ``log_var_encoder.*``,
+``normalized_mean_decoder.0.*``, ``log_concentration``) so that checkpoints interchange.
+Only the variants the shipped configs select are provided.
+"""
+from __future__ import annotations
+
+from typing import Literal
+
+import torch
+from torch import nn
+
+from . import functional as F_hip
+from .distributions import LibraryGammaPoisson
+
+LIKELIHOOD_KEY_DTYPE = Literal["normal", "poisson", "library_nb"]
+VAR_EPS = 1e-4
+
+
+def nan_to_num_ref(t: torch.Tensor) -> torch.Tensor:
+    return torch.nan_to_num(t, nan=1e-6, posinf=1e6, neginf=1e-6)
+
+
+class ResidualMLP(nn.Module):
+    """``ResidualMLP`` with ``last_layer_residual=True`` (mlp.py:83-119): LeakyReLU after every
+    Linear, residual connection on every layer but the first."""
+
+    def __init__(self, n_input: int, n_output: int, n_layers: int, n_hidden: int):
+        super().__init__()
+        dims = [n_input] + n_layers * [n_hidden] + [n_output]  # mlp.py:58
+        assert n_output == n_hidden  # mlp.py:109
+        self.layers = nn.ModuleList(
+            [nn.Sequential(nn.Linear(dims[i - 1], dims[i]), nn.LeakyReLU()) for i in range(1, len(dims))]
+        )
+
+    def linears(self):
+        return [layer[0] for layer in self.layers]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        for i, lin in enumerate(self.linears()):
+            x = F_hip.linear(x, lin.weight, lin.bias, act=True, residual=None if i == 0 else x)
+        return x
+
+
+class GaussianLikelihoodResidualMLP(nn.Module):
+    """mlp.py:217-243 + BaseGaussianLikelihoodMLP.forward :122-142 -> torch Normal."""
+
+    def __init__(self, n_input: int, n_output: int, n_layers: int, n_hidden: int, var_eps: float = VAR_EPS):
+        super().__init__()
+        self.mlp = ResidualMLP(n_input, n_hidden, n_layers - 1, n_hidden)
+        self.mean_encoder = nn.Linear(n_hidden, n_output)
+        self.log_var_encoder = nn.Linear(n_hidden, n_output)
+        self.var_eps = var_eps
+
+    def mean_var(self, x: torch.Tensor):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        z = self.mlp(x2)
+        mean = F_hip.linear(z, self.mean_encoder.weight, self.mean_encoder.bias)
+        var = torch.exp(F_hip.linear(z, self.log_var_encoder.weight, self.log_var_encoder.bias)) + self.var_eps
+        mean = nan_to_num_ref(mean.reshape(*shape[:-1], -1))
+        var = nan_to_num_ref(torch.abs(var.reshape(*shape[:-1], -1)))
+        return mean, var
+
+    def forward(self, x: torch.Tensor) -> torch.distributions.Normal:
+        mean, var = self.mean_var(x)
+        return torch.distributions.Normal(mean, var.sqrt(), validate_args=False)
+
+
+class LibraryGammaPoissonSharedConcentrationResidualMLP(nn.Module):
+    """mlp.py:286-317 + forward :145-168.  Returns a ``LibraryGammaPoisson`` that keeps the
+    pre-softmax logits so that ``log_prob`` runs the fused HIP kernel."""
+
+    def __init__(self, n_input: int, n_output: int, n_layers: int, n_hidden: int):
+        super().__init__()
+        self.mlp = ResidualMLP(n_input, n_hidden, n_layers - 1, n_hidden)
+        # the Softmax module has no parameters; it keeps the reference's key "normalized_mean_decoder.0"
+        self.normalized_mean_decoder = nn.Sequential(nn.Linear(n_hidden, n_output), nn.Softmax(dim=-1))
+        self.log_concentration = nn.Parameter(torch.zeros((n_output,)))
+
+    def forward(self, x: torch.Tensor, library_size: torch.Tensor) -> LibraryGammaPoisson:
+        if x.dim() == 3:
+            P, n, _ = x.shape
+        else:
+            P, n = 1, x.shape[0]
+        h = self.mlp(x.reshape(P * n, -1))
+        lin = self.normalized_mean_decoder[0]
+        logits = F_hip.linear(h, lin.weight, lin.bias)
+        batch_shape = (P, n) if x.dim() == 3 else (n,)
+        return LibraryGammaPoisson(logits, library_size.reshape(-1), self.log_concentration, P, n, batch_shape)
+
+
+def get_likelihood_mlp(likelihood_key: LIKELIHOOD_KEY_DTYPE, n_input: int, n_output: int, n_layers: int,
+                       n_hidden: int, use_batch_norm: bool = False, activation_fn=nn.LeakyReLU) -> nn.Module:
+    """mlp.py:12-40 for the keys the shipped configs use."""
+    if use_batch_norm or activation_fn is not nn.LeakyReLU:
+        raise NotImplementedError("cradle_vae_amd: only LeakyReLU MLPs without batch norm are on the HIP path")
+    if likelihood_key == "normal":
+        return GaussianLikelihoodResidualMLP(n_input, n_output, n_layers, n_hidden)
+    if likelihood_key == "library_nb":
+        return LibraryGammaPoissonSharedConcentrationResidualMLP(n_input, n_output, n_layers, n_hidden)
+    raise NotImplementedError(
+        f"likelihood_key={likelihood_key!r}: no shipped CRADLE-VAE config selects it; out of the HIP path's scope"
+    )

@@ -11,6 +11,27 @@ import torch
 
 from . import hip
 
+# Optional HIP-event timing of individual launches (bench.py: roofline of K1).  Events are
+# recorded on the stream the kernel is launched on (torch's current stream).
+KERNEL_TIMING = False
+KERNEL_TIMERS = []  # (name, start_event, end_event)
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_TIMING:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *exc):
+        if KERNEL_TIMING:
+            self.e.record()
+            KERNEL_TIMERS.append((self.name, self.s, self.e))
+
 
 def nb_gene_consts(log_concentration: torch.Tensor) -> torch.Tensor:
     """(G,) log-concentration -> (3,G) [c, lgamma(c), digamma(c)]  (mlp.py:160)."""
@@ -58,13 +79,14 @@ def nb_logprob_fwd_bwd(
     need = lib_.cradle_nb_workspace_floats(P, N, G)
     if workspace is None:
         workspace = torch.empty((need,), device=X.device, dtype=torch.float32)
-    hip.check(
-        lib_.cradle_nb_logprob_fwd_bwd(
-            hip.ptr(logits), logits.stride(0), hip.ptr(dlogits), dlogits.stride(0), hip.ptr(X), X.stride(0),
-            hip.ptr(lib), hip.ptr(gene_consts), hip.ptr(grow), hip.ptr(out), hip.ptr(dlog_c), int(accumulate),
-            hip.ptr(workspace), workspace.numel(), P, N, G, hip.stream()),
-        "nb_logprob_fwd_bwd",
-    )
+    with _timed("nb_logprob_fwd_bwd"):
+        hip.check(
+            lib_.cradle_nb_logprob_fwd_bwd(
+                hip.ptr(logits), logits.stride(0), hip.ptr(dlogits), dlogits.stride(0), hip.ptr(X), X.stride(0),
+                hip.ptr(lib), hip.ptr(gene_consts), hip.ptr(grow), hip.ptr(out), hip.ptr(dlog_c), int(accumulate),
+                hip.ptr(workspace), workspace.numel(), P, N, G, hip.stream()),
+            "nb_logprob_fwd_bwd",
+        )
     return out, dlogits, dlog_c
 
 

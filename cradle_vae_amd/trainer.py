@@ -1,0 +1,75 @@
+"""One training step = ELBO loss + backward + gradient all-reduce + norm clip + Adam.
+
+What Lightning does around ``training_step`` in the reference (``pl.Trainer(gradient_clip_val=
+100)`` train_norman.py:89-97, ``configure_optimizers`` perturbation_lightning_module.py:
+147-150: Adam with L2 weight decay 1e-6), as an explicit loop body that works without
+pytorch_lightning and with one process per GPU (``torch.distributed``, RCCL).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+
+class TrainStep:
+    def __init__(self, loss_module, lr: float, weight_decay: float = 1e-6,
+                 gradient_clip_norm: Optional[float] = 100.0, world_size: int = 1, seed: int = 0):
+        self.lm = loss_module
+        self.world_size = world_size
+        self.clip = gradient_clip_norm
+        self.params = [p for p in loss_module.parameters() if p.requires_grad]
+        self.optimizer = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay)
+        self.device = self.params[0].device
+        # plated draws (mask, E, qc_E) must agree across ranks, local draws (z_basal) must not:
+        # two generators, the first seeded identically everywhere
+        self.gen_plated = torch.Generator(device=self.device).manual_seed(seed)
+        rank = torch.distributed.get_rank() if world_size > 1 else 0
+        self.gen_local = torch.Generator(device=self.device).manual_seed(seed + 7919 * (rank + 1))
+        self.impl = "modular"
+        self.decoder_variants = 2
+
+    def draw_noise(self, P, N):
+        g = self.lm.guide
+        T, L, Q = g.n_treatments, g.n_latent, g.n_qc
+        d = self.device
+
+        def one():
+            return dict(
+                u_mask=torch.rand((P, T, L), device=d, generator=self.gen_plated),
+                eps_E=torch.randn((P, T, L), device=d, generator=self.gen_plated),
+                eps_qc_E=torch.randn((P, Q, L), device=d, generator=self.gen_plated),
+                eps_z=torch.randn((P, N, L), device=d, generator=self.gen_local),
+            )
+
+        return one(), one()
+
+    def allreduce_grads(self):
+        if self.world_size == 1:
+            return
+        import torch.distributed as dist
+
+        flat = torch.cat([p.grad.reshape(-1) for p in self.params])
+        dist.all_reduce(flat)
+        flat.div_(self.world_size)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p))
+            off += n
+
+    def __call__(self, batch: Dict[str, torch.Tensor], n_particles: int) -> torch.Tensor:
+        noise, cf_noise = self.draw_noise(n_particles, batch["X"].shape[0])
+        self.optimizer.zero_grad(set_to_none=False)
+        loss, metrics = self.lm.loss(
+            X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"],
+            qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"],
+            condition_values={"library_size": batch["library_size"]}, n_particles=n_particles, noise=noise,
+            cf_noise=cf_noise)
+        loss.backward()
+        self.allreduce_grads()
+        if self.clip is not None:
+            torch.nn.utils.clip_grad_norm_(self.params, self.clip)
+        self.optimizer.step()
+        self.last_metrics = metrics
+        return loss.detach()
