@@ -1,0 +1,836 @@
+// K2-K5, K7, K8: the sampling, log-ratio, gather/scatter and bookkeeping kernels of the ELBO
+// step.  All HBM/latency-bound elementwise or row-reduction work on small tensors; each kernel
+// fuses what the reference spreads over a chain of ATen launches and keeps forward values the
+// backward needs.  Reference lines are cited per kernel (paths relative to /root/reference).
+#include "common.h"
+#include "kernels.h"
+
+namespace cradle {
+
+constexpr float kEps32 = 1.1920928955078125e-07f;  // torch.finfo(float32).eps: clamp_probs
+constexpr float kVarEps = 1e-4f;                   // mlp.py:227
+
+__device__ __forceinline__ float clamp_probs(float p) { return fminf(fmaxf(p, kEps32), 1.0f - kEps32); }
+__device__ __forceinline__ bool interior(float p) { return p > kEps32 && p < 1.0f - kEps32; }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ bool finitef_(float x) { return fabsf(x) <= 3.4028234663852886e38f; }
+
+// =====================================================================================
+// Dosage plan: dense D (N,T) -> ELL rows (gather) + CSC columns (scatter) + per-treatment counts.
+// D reaches the step dense (batch contract, data/utils/perturbation_dataset.py:85-89) but has
+// <= 2 non-zeros per row (data/norman/data_module.py:100-102); every matmul(D, .) of the
+// reference (model.py:118-122, correlated_normal_guide.py:186-188, loss_modules.py:224-232) is
+// evaluated from this plan.  Entry order is (cell, column) ascending, so sums are deterministic.
+// =====================================================================================
+__global__ __launch_bounds__(64) void dosage_rows_kernel(const float* __restrict__ D, int N, int T, int kmax,
+                                                         int* __restrict__ ell_idx, float* __restrict__ ell_val,
+                                                         int* __restrict__ tcount, int* __restrict__ flags) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  int base = 0;
+  for (int c = 0; c < T; c += 64) {
+    const int t = c + lane;
+    const float v = t < T ? D[(int64_t)n * T + t] : 0.f;
+    const bool nz = v != 0.f;
+    const unsigned long long b = __ballot(nz);
+    const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
+    if (nz) {
+      atomicAdd(&tcount[t], 1);
+      if (pos < kmax) {
+        ell_idx[n * kmax + pos] = t;
+        ell_val[n * kmax + pos] = v;
+      }
+    }
+    base += __popcll(b);
+  }
+  for (int k = base + lane; k < kmax; k += 64) {
+    ell_idx[n * kmax + k] = -1;
+    ell_val[n * kmax + k] = 0.f;
+  }
+  if (lane == 0 && base > kmax) atomicOr(flags, 1);
+}
+
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int* __restrict__ tcount, int T, int* __restrict__ tstart) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int c = 0; c < T; c += 1024) {
+    const int t = c + threadIdx.x;
+    const int v = t < T ? tcount[t] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (t < T) tstart[t] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tstart[T] = carry;
+}
+
+__global__ __launch_bounds__(256) void csc_fill_kernel(const int* __restrict__ ell_idx, const float* __restrict__ ell_val,
+                                                       int entries, int kmax, int T, const int* __restrict__ tstart,
+                                                       int* __restrict__ csc_cell, float* __restrict__ csc_val) {
+  __shared__ int sidx[4096];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  int pos = t < T ? tstart[t] : 0;
+  for (int c = 0; c < entries; c += 4096) {
+    const int m = min(4096, entries - c);
+    for (int i = threadIdx.x; i < m; i += 256) sidx[i] = ell_idx[c + i];
+    __syncthreads();
+    if (t < T) {
+      for (int i = 0; i < m; ++i) {
+        if (sidx[i] == t) {
+          csc_cell[pos] = (c + i) / kmax;
+          csc_val[pos] = ell_val[c + i];
+          ++pos;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int build_dosage_plan(const float* D, int N, int T, const DosagePlan& plan, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(plan.tcount, 0, sizeof(int) * T, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(plan.flags, 0, sizeof(int), stream);
+  if (e != hipSuccess) {
+    cradle_set_error("build_dosage_plan: memset failed: %s", hipGetErrorString(e));
+    return CRADLE_ERR_HIP;
+  }
+  hipLaunchKernelGGL(dosage_rows_kernel, dim3(N), dim3(64), 0, stream, D, N, T, plan.kmax, plan.ell_idx, plan.ell_val,
+                     plan.tcount, plan.flags);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, plan.tcount, T, plan.tstart);
+  hipLaunchKernelGGL(csc_fill_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, plan.ell_idx, plan.ell_val,
+                     N * plan.kmax, plan.kmax, T, plan.tstart, plan.csc_cell, plan.csc_val);
+  CRADLE_CHECK_LAUNCH("build_dosage_plan");
+  return CRADLE_OK;
+}
+
+// =====================================================================================
+// Per-cell weights of loss_modules.py:137-143 and the plate reweighting of :200-232.
+//   alpha = self.alpha or qc.sum()/N;  qc <- max over columns if Q > 1
+//   recon = alpha (1-qc) logp_good + (1-alpha) qc logp_bad   (qc in {0,1}: one live variant per cell)
+//   plated terms: sum_n (cond[n,c] != 0)/obs[c] -> cw[c]
+// =====================================================================================
+__global__ __launch_bounds__(256) void cell_prep_kernel(const float* __restrict__ qc, const float* __restrict__ D_obs,
+                                                        const float* __restrict__ qc_obs, const int* __restrict__ tcount,
+                                                        float alpha_fixed, int P, int N, int T, int Q, CellPrep o,
+                                                        int* __restrict__ flags) {
+  __shared__ float red[8];
+  __shared__ float red2[8];
+  float qsum = 0.f, nzc = 0.f;
+  bool bad = false;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float m = qc[(int64_t)n * Q];
+    qsum += m;
+    for (int q = 1; q < Q; ++q) {
+      const float v = qc[(int64_t)n * Q + q];
+      qsum += v;
+      m = fmaxf(m, v);
+    }
+    if (m != 0.f && m != 1.f) bad = true;
+    nzc += (m != 0.f) ? 1.f : 0.f;
+    o.live[n] = m;
+  }
+  if (bad) atomicOr(flags, 2);
+  const float tot = block_sum<256>(qsum, red);
+  const float nzt = block_sum<256>(nzc, red2);
+  const float alpha = alpha_fixed >= 0.f ? alpha_fixed : tot / (float)N;
+  const float inv_pn = 1.0f / ((float)P * (float)N);
+  if (threadIdx.x == 0) o.alpha[0] = alpha;
+  __syncthreads();  // o.live written by this block is re-read below
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float m = o.live[n];
+    const float w = alpha * (1.0f - m) + (1.0f - alpha) * m;  // exact for m in {0,1}
+    o.wrec[n] = (m != 0.f) ? (1.0f - alpha) * m : alpha * (1.0f - m);
+    (void)w;
+    for (int p = 0; p < P; ++p) o.grow[(int64_t)p * N + n] = -o.wrec[n] * inv_pn;
+  }
+  for (int t = threadIdx.x; t < T; t += 256) {
+    float s = 1.0f / D_obs[t];
+    if (isinf(s)) s = 0.f;
+    const float c = (float)tcount[t] * s;
+    o.cw[t] = c;
+    o.coefT[t] = -c * inv_pn;
+  }
+  for (int q = threadIdx.x; q < Q; q += 256) {
+    float s = 1.0f / qc_obs[q];
+    if (isinf(s)) s = 0.f;
+    const float c = nzt * s;
+    o.cwq[q] = c;
+    o.coefQ[q] = -c * inv_pn;
+  }
+}
+
+int cell_prep(const float* qc, const float* D_obs, const float* qc_obs, const int* tcount, float alpha_fixed, int P,
+              int N, int T, int Q, const CellPrep& out, int* flags, hipStream_t stream) {
+  hipLaunchKernelGGL(cell_prep_kernel, dim3(1), dim3(256), 0, stream, qc, D_obs, qc_obs, tcount, alpha_fixed, P, N, T, Q,
+                     out, flags);
+  CRADLE_CHECK_LAUNCH("cell_prep_kernel");
+  return CRADLE_OK;
+}
+
+// =====================================================================================
+// K8 LogStandardizationModule.forward (normalization.py:41-45) for X and cfX in one launch,
+// plus the "has a counterfactual" flag of loss_modules.py:145 (cfX.sum(1) != 0).
+// =====================================================================================
+__global__ __launch_bounds__(256) void log_standardize_kernel(const float* __restrict__ X, const float* __restrict__ cfX,
+                                                              const float* __restrict__ mean, const float* __restrict__ scale,
+                                                              float* __restrict__ xn, float* __restrict__ hascf, int N, int G) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const float* src = r < N ? X + (int64_t)r * G : cfX + (int64_t)(r - N) * G;
+  float* dst = xn + (int64_t)r * G;
+  float s = 0.f;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    const float x = src[g];
+    s += x;
+    dst[g] = nan_to_num_ref((logf(x + 1.0f) - mean[g]) / scale[g]);
+  }
+  if (r >= N) {
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) hascf[r - N] = (s != 0.f) ? 1.f : 0.f;
+  }
+}
+
+int log_standardize(const float* X, const float* cfX, const float* log_mean, const float* log_scale, float* xn,
+                    float* hascf, int N, int G, hipStream_t stream) {
+  hipLaunchKernelGGL(log_standardize_kernel, dim3(2 * N), dim3(256), 0, stream, X, cfX, log_mean, log_scale, xn, hascf, N, G);
+  CRADLE_CHECK_LAUNCH("log_standardize_kernel");
+  return CRADLE_OK;
+}
+
+// =====================================================================================
+// K3 q(M): relaxed-Bernoulli straight-through sample + Bernoulli log-ratio.
+//   gumbel_softmax_bernoulli.py:5-17 over pyro RelaxedBernoulliStraightThrough (pyro-ppl 1.9.1)
+//   over torch LogitRelaxedBernoulli.rsample; guide call correlated_normal_guide.py:132-141;
+//   prior Bernoulli(logits=logit(p0)) model.py:96; log-ratio loss_modules.py:160-161.
+// One wave per (particle, treatment) row; S[row] = sum_l log p(m) - log q(m).
+// =====================================================================================
+__device__ __forceinline__ float sanitize(float v) { return finitef_(v) ? v : 0.f; }
+
+__global__ __launch_bounds__(256) void mask_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ u,
+                                                       const float* __restrict__ p0, float tau, float* __restrict__ mask,
+                                                       float* __restrict__ soft, float* __restrict__ S, int rows, int T, int L) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int t = row % T;
+  float acc = 0.f;
+  for (int l = lane; l < L; l += 64) {
+    const float lg = sanitize(logits[t * L + l]);
+    const float p = clamp_probs(sigmoidf_(lg));
+    const float lq = logf(p) - log1pf(-p);
+    const float uu = clamp_probs(u[(int64_t)row * L + l]);
+    const float y = (logf(uu) - log1pf(-uu) + lq) / tau;
+    const float s = clamp_probs(sigmoidf_(y));
+    const float m = rintf(s);
+    mask[(int64_t)row * L + l] = m;
+    soft[(int64_t)row * L + l] = s;
+    const float pp = p0[t * L + l];
+    const float lp = logf(pp / (1.0f - pp));  // torch.logit
+    acc += (m * lp - softplusf_(lp)) - (m * lq - softplusf_(lq));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) S[row] = acc;
+}
+
+int mask_fwd(const float* logits, const float* u, const float* p_mask_probs, float tau, float* mask, float* soft,
+             float* S, int PP, int T, int L, hipStream_t stream) {
+  const int rows = PP * T;
+  hipLaunchKernelGGL(mask_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, u, p_mask_probs, tau, mask, soft,
+                     S, rows, T, L);
+  CRADLE_CHECK_LAUNCH("mask_fwd_kernel");
+  return CRADLE_OK;
+}
+
+// d loss / d q_mask_logits.  dmask_a/dmask_b: gradients reaching the hard sample from mask*E and
+// from the embedding encoder's input; coefT[t] = -cw[t]/(P N) weights the log-ratio term of the
+// main pass (particles pp < P).  Straight-through: the hard sample's gradient lands on the soft
+// sample.  One thread per (t, l), particles summed in order (deterministic).
+__global__ __launch_bounds__(256) void mask_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ p0,
+                                                       float tau, const float* __restrict__ mask, const float* __restrict__ soft,
+                                                       const float* __restrict__ da, const float* __restrict__ db,
+                                                       const float* __restrict__ coefT, float* __restrict__ dlogits, int PP,
+                                                       int P, int T, int L) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= T * L) return;
+  const int t = i / L;
+  const float raw = logits[i];
+  if (!finitef_(raw)) {  // sanitize_tensor replaced it by a constant
+    dlogits[i] = 0.f;
+    return;
+  }
+  const float pr = sigmoidf_(raw);
+  const bool p_in = interior(pr);
+  const float p = clamp_probs(pr);
+  const float lq = logf(p) - log1pf(-p);
+  const float pp0 = p0[i];
+  const float lp = logf(pp0 / (1.0f - pp0));
+  const float ct = coefT[t];
+  float g = 0.f;
+  for (int pp = 0; pp < PP; ++pp) {
+    const int64_t j = (int64_t)pp * T * L + i;
+    const float m = mask[j], s = soft[j];
+    float dm = da[j] + db[j];
+    if (pp < P) dm += ct * (lp - lq);          // d/dm [log p(m) - log q(m)]
+    const float dy = interior(s) ? dm * s * (1.0f - s) : 0.f;
+    float dl = dy / tau;                        // through logit(clamp(sigmoid(logits)))
+    if (pp < P) dl += ct * (-(m - p));          // d/d logit_q [-log q(m)]
+    if (p_in) g += dl;
+  }
+  dlogits[i] = g;
+}
+
+int mask_bwd(const float* logits, const float* p_mask_probs, float tau, const float* mask, const float* soft,
+             const float* dmask_a, const float* dmask_b, const float* coefT, float* dlogits, int PP, int P, int T, int L,
+             hipStream_t stream) {
+  hipLaunchKernelGGL(mask_bwd_kernel, dim3((T * L + 255) / 256), dim3(256), 0, stream, logits, p_mask_probs, tau, mask,
+                     soft, dmask_a, dmask_b, coefT, dlogits, PP, P, T, L);
+  CRADLE_CHECK_LAUNCH("mask_bwd_kernel");
+  return CRADLE_OK;
+}
+
+// =====================================================================================
+// K2 Gaussian heads: BaseGaussianLikelihoodMLP.forward tail (mlp.py:131-141), rsample
+// (correlated_normal_guide.py:157,166,202-204) and the Normal log-ratio of loss_modules.py:
+// 160-161.  heads row = [mean_raw (L) | log_var_raw (L)].
+//   var = nan_to_num(|exp(lv)+1e-4|), mean = nan_to_num(mean_raw), sd = sqrt(var), s = mean + sd*eps
+//   log N(ploc,pscale)(s) - log N(mean,sd)(s) = -(s-ploc)^2/(2 pscale^2) - log pscale + eps^2/2 + log sd
+// =====================================================================================
+struct GaussVals {
+  float mean, sd, e;
+  bool mean_ok, var_ok;
+};
+__device__ __forceinline__ GaussVals gauss_vals(float mean_raw, float lv_raw) {
+  GaussVals g;
+  g.e = expf(lv_raw);
+  const float var_raw = fabsf(g.e + kVarEps);
+  g.var_ok = finitef_(var_raw) && !(var_raw != var_raw);
+  g.mean_ok = finitef_(mean_raw) && !(mean_raw != mean_raw);
+  g.mean = nan_to_num_ref(mean_raw);
+  g.sd = sqrtf(nan_to_num_ref(var_raw));
+  return g;
+}
+
+// q(E|M): rows = PP*T, also writes mask*E for the gathers (model.py:121, guide :186-188).
+__global__ __launch_bounds__(256) void gaussE_fwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
+                                                         const float* __restrict__ mask, const float* __restrict__ ploc,
+                                                         const float* __restrict__ pscale, float* __restrict__ E,
+                                                         float* __restrict__ sd, float* __restrict__ ME, float* __restrict__ S,
+                                                         int rows, int T, int L) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int t = row % T;
+  float acc = 0.f;
+  for (int l = lane; l < L; l += 64) {
+    const GaussVals g = gauss_vals(heads[(int64_t)row * 2 * L + l], heads[(int64_t)row * 2 * L + L + l]);
+    const float ep = eps[(int64_t)row * L + l];
+    const float s = g.mean + g.sd * ep;
+    E[(int64_t)row * L + l] = s;
+    sd[(int64_t)row * L + l] = g.sd;
+    ME[(int64_t)row * L + l] = s * mask[(int64_t)row * L + l];
+    const float pl = ploc[t * L + l], ps = pscale[t * L + l];
+    const float d = s - pl;
+    acc += -(d * d) / (2.0f * ps * ps) - logf(ps) + 0.5f * ep * ep + logf(g.sd);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) S[row] = acc;
+}
+
+int gaussE_fwd(const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale, float* E,
+               float* sd, float* ME, float* S, int PP, int T, int L, hipStream_t stream) {
+  const int rows = PP * T;
+  hipLaunchKernelGGL(gaussE_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, heads, eps, mask, ploc, pscale, E, sd,
+                     ME, S, rows, T, L);
+  CRADLE_CHECK_LAUNCH("gaussE_fwd_kernel");
+  return CRADLE_OK;
+}
+
+__device__ __forceinline__ void gauss_head_grads(const GaussVals& g, float ds, float ep, float c_over_sd, float& dmean,
+                                                 float& dlv) {
+  dmean = g.mean_ok ? ds : 0.f;
+  const float dsd = ds * ep + c_over_sd;
+  dlv = g.var_ok ? dsd * g.e / (2.0f * g.sd) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void gaussE_bwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
+                                                         const float* __restrict__ mask, const float* __restrict__ ploc,
+                                                         const float* __restrict__ pscale, const float* __restrict__ E,
+                                                         const float* __restrict__ sd, const float* __restrict__ dME,
+                                                         const float* __restrict__ coefT, float* __restrict__ dheads,
+                                                         float* __restrict__ dmask, int PP, int P, int T, int L) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)PP * T * L) return;
+  const int l = i % L;
+  const int64_t row = i / L;
+  const int t = row % T, pp = row / T;
+  const GaussVals g = gauss_vals(heads[row * 2 * L + l], heads[row * 2 * L + L + l]);
+  const float s = E[i], ep = eps[i], dme = dME[i];
+  const float coef = pp < P ? coefT[t] : 0.f;
+  const float pl = ploc[t * L + l], ps = pscale[t * L + l];
+  const float ds = dme * mask[i] + coef * (-(s - pl) / (ps * ps));
+  dmask[i] = dme * s;
+  float dmean, dlv;
+  gauss_head_grads(g, ds, ep, coef / sd[i], dmean, dlv);
+  dheads[row * 2 * L + l] = dmean;
+  dheads[row * 2 * L + L + l] = dlv;
+}
+
+int gaussE_bwd(const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale,
+               const float* E, const float* sd, const float* dME, const float* coefT, float* dheads, float* dmask, int PP,
+               int P, int T, int L, hipStream_t stream) {
+  const int64_t n = (int64_t)PP * T * L;
+  hipLaunchKernelGGL(gaussE_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, heads, eps, mask, ploc,
+                     pscale, E, sd, dME, coefT, dheads, dmask, PP, P, T, L);
+  CRADLE_CHECK_LAUNCH("gaussE_bwd_kernel");
+  return CRADLE_OK;
+}
+
+// q(qc_E): the encoder input is the constant ones(Q,L) (correlated_normal_guide.py:74,162), so
+// its heads (Q, 2L) are shared by all particles of both guide passes.  qsum[p] = sum_q qc_E[p,q]
+// is the bad-variant latent shift of model.py:122 (ones(qc.shape) @ qc_E).
+__global__ __launch_bounds__(256) void qce_fwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
+                                                      const float* __restrict__ ploc, const float* __restrict__ pscale,
+                                                      float* __restrict__ qcE, float* __restrict__ sd, float* __restrict__ S,
+                                                      float* __restrict__ qsum, int PP, int P, int Q, int L) {
+  // one block per particle pp; threads over l; loop q (Q is 1..6)
+  __shared__ float red[4];
+  const int pp = blockIdx.x;
+  for (int q = 0; q < Q; ++q) {
+    float acc = 0.f;
+    for (int l = threadIdx.x; l < L; l += 256) {
+      const GaussVals g = gauss_vals(heads[q * 2 * L + l], heads[q * 2 * L + L + l]);
+      const int64_t i = ((int64_t)pp * Q + q) * L + l;
+      const float ep = eps[i];
+      const float s = g.mean + g.sd * ep;
+      qcE[i] = s;
+      if (pp == 0) sd[q * L + l] = g.sd;
+      const float pl = ploc[q * L + l], ps = pscale[q * L + l];
+      const float d = s - pl;
+      acc += -(d * d) / (2.0f * ps * ps) - logf(ps) + 0.5f * ep * ep + logf(g.sd);
+    }
+    acc = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) S[pp * Q + q] = acc;
+    __syncthreads();
+  }
+  if (pp < P) {
+    for (int l = threadIdx.x; l < L; l += 256) {
+      float s = 0.f;
+      for (int q = 0; q < Q; ++q) s += qcE[((int64_t)pp * Q + q) * L + l];
+      qsum[pp * L + l] = s;
+    }
+  }
+}
+
+int qce_fwd(const float* heads, const float* eps, const float* ploc, const float* pscale, float* qcE, float* sd, float* S,
+            float* qsum, int PP, int P, int Q, int L, hipStream_t stream) {
+  hipLaunchKernelGGL(qce_fwd_kernel, dim3(PP), dim3(256), 0, stream, heads, eps, ploc, pscale, qcE, sd, S, qsum, PP, P, Q, L);
+  CRADLE_CHECK_LAUNCH("qce_fwd_kernel");
+  return CRADLE_OK;
+}
+
+// dq_enc (PP*Q, L): gradient from the basal encoder's qc offsets; dq_dec (P, L): gradient from the
+// decoder's bad-variant shift (same for every q).  Sums over particles in order -> (Q, 2L).
+__global__ __launch_bounds__(256) void qce_bwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
+                                                      const float* __restrict__ ploc, const float* __restrict__ pscale,
+                                                      const float* __restrict__ qcE, const float* __restrict__ sd,
+                                                      const float* __restrict__ dq_enc, const float* __restrict__ dq_dec,
+                                                      const float* __restrict__ coefQ, float* __restrict__ dheads, int PP,
+                                                      int P, int Q, int L) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Q * L) return;
+  const int q = i / L, l = i % L;
+  const GaussVals g = gauss_vals(heads[q * 2 * L + l], heads[q * 2 * L + L + l]);
+  const float pl = ploc[i], ps = pscale[i], sdv = sd[i], cq = coefQ[q];
+  float gm = 0.f, gv = 0.f;
+  for (int pp = 0; pp < PP; ++pp) {
+    const int64_t j = ((int64_t)pp * Q + q) * L + l;
+    const float s = qcE[j], ep = eps[j];
+    float ds = dq_enc[j];
+    float coef = 0.f;
+    if (pp < P) {
+      ds += dq_dec[pp * L + l];
+      coef = cq;
+      ds += coef * (-(s - pl) / (ps * ps));
+    }
+    float dmean, dlv;
+    gauss_head_grads(g, ds, ep, coef / sdv, dmean, dlv);
+    gm += dmean;
+    gv += dlv;
+  }
+  dheads[q * 2 * L + l] = gm;
+  dheads[q * 2 * L + L + l] = gv;
+}
+
+int qce_bwd(const float* heads, const float* eps, const float* ploc, const float* pscale, const float* qcE,
+            const float* sd, const float* dq_enc, const float* dq_dec, const float* coefQ, float* dheads, int PP, int P,
+            int Q, int L, hipStream_t stream) {
+  hipLaunchKernelGGL(qce_bwd_kernel, dim3((Q * L + 255) / 256), dim3(256), 0, stream, heads, eps, ploc, pscale, qcE, sd,
+                     dq_enc, dq_dec, coefQ, dheads, PP, P, Q, L);
+  CRADLE_CHECK_LAUNCH("qce_bwd_kernel");
+  return CRADLE_OK;
+}
+
+// q(z_basal | ...) head + K7 counterfactual KL, one wave per (particle, cell).
+//   heads rows: [0,PN) main pass q_z_basal, [PN,2PN) main pass q_z_cf_basal,
+//               [2PN,3PN) counterfactual pass q_z_basal        (correlated_normal_guide.py:196-204)
+//   z = mean + sd*eps; ltz = sum_l log N(0,1)(z) - log N(mean,sd)(z)            (loss_modules.py:160-161)
+//   KL (loss_modules.py:145-151,190-196): on cells with cfX.sum != 0, with 1 = cf pass, 2 = q_z_cf_basal:
+//     beta * sum_l mean_p sum_n -0.5 (1 + lv1 - lv2 - (mu1-mu2)^2 - exp(lv1-lv2)),  lv = 2 log sd
+//   The KL branches have no other consumer, so their head gradients are written here already.
+__global__ __launch_bounds__(256) void zhead_fwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
+                                                        const float* __restrict__ hascf, float kl_coef, float* __restrict__ z,
+                                                        int64_t ldz, float* __restrict__ sd, float* __restrict__ ltz,
+                                                        float* __restrict__ klrow, float* __restrict__ dheads, int P, int N,
+                                                        int L) {
+  const int64_t PN = (int64_t)P * N;
+  const int64_t r0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r0 >= PN) return;
+  const int n = r0 % N;
+  const int64_t r1 = PN + r0, r2 = 2 * PN + r0;
+  const bool cf = hascf[n] != 0.f;
+  float a_lt = 0.f, a_kl = 0.f;
+  for (int l = lane; l < L; l += 64) {
+    const GaussVals g = gauss_vals(heads[r0 * 2 * L + l], heads[r0 * 2 * L + L + l]);
+    const float ep = eps[r0 * L + l];
+    const float zz = g.mean + g.sd * ep;
+    z[r0 * ldz + l] = zz;
+    sd[r0 * L + l] = g.sd;
+    a_lt += -0.5f * zz * zz + 0.5f * ep * ep + logf(g.sd);
+    float dm1 = 0.f, dv1 = 0.f, dm2 = 0.f, dv2 = 0.f;
+    if (cf) {
+      const GaussVals g2 = gauss_vals(heads[r1 * 2 * L + l], heads[r1 * 2 * L + L + l]);  // q_z_cf_basal
+      const GaussVals g1 = gauss_vals(heads[r2 * 2 * L + l], heads[r2 * 2 * L + L + l]);  // cf pass q_z_basal
+      const float lv1 = 2.0f * logf(g1.sd), lv2 = 2.0f * logf(g2.sd);
+      const float dmu = g1.mean - g2.mean;
+      const float ratio = expf(lv1 - lv2);
+      a_kl += -0.5f * (1.0f + lv1 - lv2 - dmu * dmu - ratio);
+      // d/d(mean), d/d(lv) then lv = log(exp(lv_raw) + 1e-4): d lv / d lv_raw = e / var
+      dm1 = g1.mean_ok ? kl_coef * dmu : 0.f;
+      dm2 = g2.mean_ok ? -kl_coef * dmu : 0.f;
+      dv1 = g1.var_ok ? kl_coef * (-0.5f) * (1.0f - ratio) * g1.e / (g1.sd * g1.sd) : 0.f;
+      dv2 = g2.var_ok ? kl_coef * (-0.5f) * (ratio - 1.0f) * g2.e / (g2.sd * g2.sd) : 0.f;
+    }
+    dheads[r1 * 2 * L + l] = dm2;
+    dheads[r1 * 2 * L + L + l] = dv2;
+    dheads[r2 * 2 * L + l] = dm1;
+    dheads[r2 * 2 * L + L + l] = dv1;
+  }
+  a_lt = wave_sum(a_lt);
+  a_kl = wave_sum(a_kl);
+  if (lane == 0) {
+    ltz[r0] = a_lt;
+    klrow[r0] = a_kl;
+  }
+}
+
+int zhead_fwd(const float* heads, const float* eps, const float* hascf, float beta, float* z, int64_t ldz, float* sd,
+              float* ltz, float* klrow, float* dheads, int P, int N, int L, hipStream_t stream) {
+  const int64_t rows = (int64_t)P * N;
+  hipLaunchKernelGGL(zhead_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, heads, eps, hascf,
+                     beta / (float)P, z, ldz, sd, ltz, klrow, dheads, P, N, L);
+  CRADLE_CHECK_LAUNCH("zhead_fwd_kernel");
+  return CRADLE_OK;
+}
+
+// main-pass q_z_basal head gradient: dz from the decoder + the ltz term (weight -1/(P N)).
+__global__ __launch_bounds__(256) void zhead_bwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
+                                                        const float* __restrict__ z, int64_t ldz, const float* __restrict__ sd,
+                                                        const float* __restrict__ dz, int64_t lddz, float* __restrict__ dheads,
+                                                        int64_t PN, int L, float coef) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= PN * L) return;
+  const int64_t r = i / L;
+  const int l = i % L;
+  const GaussVals g = gauss_vals(heads[r * 2 * L + l], heads[r * 2 * L + L + l]);
+  const float ds = dz[r * lddz + l] + coef * (-z[r * ldz + l]);
+  float dmean, dlv;
+  gauss_head_grads(g, ds, eps[i], coef / sd[i], dmean, dlv);
+  dheads[r * 2 * L + l] = dmean;
+  dheads[r * 2 * L + L + l] = dlv;
+}
+
+int zhead_bwd(const float* heads, const float* eps, const float* z, int64_t ldz, const float* sd, const float* dz,
+              int64_t lddz, float* dheads, int P, int N, int L, hipStream_t stream) {
+  const int64_t PN = (int64_t)P * N;
+  hipLaunchKernelGGL(zhead_bwd_kernel, dim3((unsigned)((PN * L + 255) / 256)), dim3(256), 0, stream, heads, eps, z, ldz, sd,
+                     dz, lddz, dheads, PN, L, -1.0f / (float)PN);
+  CRADLE_CHECK_LAUNCH("zhead_bwd_kernel");
+  return CRADLE_OK;
+}
+
+// =====================================================================================
+// K4 gather-sum / scatter-add:  off[pp,n,:] = sum_t D[n,t] (mask*E)[pp,t,:]
+//   (model.py:121, correlated_normal_guide.py:186-188) and its transpose for the backward.
+// Particles pp < P (main pass) go to offA (a column block of the decoder input [z | off]),
+// pp >= P (counterfactual pass) to offB.
+// =====================================================================================
+__global__ __launch_bounds__(64) void gather_offsets_kernel(const float* __restrict__ ME, const int* __restrict__ ell_idx,
+                                                            const float* __restrict__ ell_val, int kmax, float* __restrict__ offA,
+                                                            int64_t ldA, float* __restrict__ offB, int64_t ldB, int P, int N,
+                                                            int T, int L) {
+  const int n = blockIdx.x, pp = blockIdx.y;
+  float* out = pp < P ? offA + ((int64_t)pp * N + n) * ldA : offB + ((int64_t)(pp - P) * N + n) * ldB;
+  const float* tab = ME + (int64_t)pp * T * L;
+  for (int l = threadIdx.x; l < L; l += 64) {
+    float acc = 0.f;
+    for (int k = 0; k < kmax; ++k) {
+      const int t = ell_idx[n * kmax + k];
+      if (t < 0) break;
+      acc = fmaf(ell_val[n * kmax + k], tab[(int64_t)t * L + l], acc);
+    }
+    out[l] = acc;
+  }
+}
+
+int gather_offsets(const float* ME, const DosagePlan& plan, float* offA, int64_t ldA, float* offB, int64_t ldB, int PP,
+                   int P, int N, int T, int L, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_offsets_kernel, dim3(N, PP), dim3(64), 0, stream, ME, plan.ell_idx, plan.ell_val, plan.kmax,
+                     offA, ldA, offB, ldB, P, N, T, L);
+  CRADLE_CHECK_LAUNCH("gather_offsets_kernel");
+  return CRADLE_OK;
+}
+
+// dME[pp,t,:] = sum_{cells n of t} D[n,t] * (a1 + a2)[pp,n,:]   (pp < P)   or  b1[pp-P,n,:]  (pp >= P)
+__global__ __launch_bounds__(64) void scatter_offsets_kernel(const int* __restrict__ tstart, const int* __restrict__ csc_cell,
+                                                             const float* __restrict__ csc_val, const float* __restrict__ a1,
+                                                             int64_t ld1, const float* __restrict__ a2, int64_t ld2,
+                                                             const float* __restrict__ b1, int64_t ldb1, float* __restrict__ dME,
+                                                             int P, int N, int T, int L) {
+  const int t = blockIdx.x, pp = blockIdx.y;
+  const int e0 = tstart[t], e1 = tstart[t + 1];
+  float* out = dME + ((int64_t)pp * T + t) * L;
+  for (int l = threadIdx.x; l < L; l += 64) {
+    float acc = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int n = csc_cell[e];
+      float g;
+      if (pp < P) g = a1[((int64_t)pp * N + n) * ld1 + l] + a2[((int64_t)pp * N + n) * ld2 + l];
+      else g = b1[((int64_t)(pp - P) * N + n) * ldb1 + l];
+      acc = fmaf(csc_val[e], g, acc);
+    }
+    out[l] = acc;
+  }
+}
+
+int scatter_offsets(const DosagePlan& plan, const float* a1, int64_t ld1, const float* a2, int64_t ld2, const float* b1,
+                    int64_t ldb1, float* dME, int PP, int P, int N, int T, int L, hipStream_t stream) {
+  hipLaunchKernelGGL(scatter_offsets_kernel, dim3(T, PP), dim3(64), 0, stream, plan.tstart, plan.csc_cell, plan.csc_val, a1,
+                     ld1, a2, ld2, b1, ldb1, dME, P, N, T, L);
+  CRADLE_CHECK_LAUNCH("scatter_offsets_kernel");
+  return CRADLE_OK;
+}
+
+// =====================================================================================
+// K5 basal-encoder first layer without materialising [x | offset | qc offset] (P,N,G+2L)
+// (correlated_normal_guide.py:196-198): pre = xW[n] + offW[pp,n] + sum_q s_q vq[pp,q] + b, where
+// xW = logstd(x) Wx^T is computed once per step for X and cfX, offW = offset W_off^T,
+// vq = qc_E W_qc^T.  Three variants, rows of h: v*P*N + p*N + n
+//   v=0 main pass q_z_basal (s = qc), v=1 main pass q_z_cf_basal (s = 1-qc),
+//   v=2 counterfactual pass q_z_basal (x = cfX, particles P..2P-1, s = 1-qc)
+// =====================================================================================
+__global__ __launch_bounds__(128) void enc_combine_fwd_kernel(const float* __restrict__ xW, const float* __restrict__ offW,
+                                                              const float* __restrict__ vq, const float* __restrict__ bias,
+                                                              const float* __restrict__ qc, float* __restrict__ h, int P,
+                                                              int N, int Q, int H) {
+  const int n = blockIdx.x, p = blockIdx.y, v = blockIdx.z;
+  const int pp = v == 2 ? P + p : p;
+  const float* xr = xW + (int64_t)(v == 2 ? N + n : n) * H;
+  const float* orow = offW + ((int64_t)pp * N + n) * H;
+  float* out = h + (((int64_t)v * P + p) * N + n) * H;
+  for (int j = threadIdx.x; j < H; j += 128) {
+    float a = xr[j] + orow[j];
+    for (int q = 0; q < Q; ++q) {
+      const float s = v == 0 ? qc[(int64_t)n * Q + q] : 1.0f - qc[(int64_t)n * Q + q];
+      a = fmaf(s, vq[((int64_t)pp * Q + q) * H + j], a);
+    }
+    a += bias[j];
+    out[j] = a > 0.f ? a : kLeakySlope * a;
+  }
+}
+
+int enc_combine_fwd(const float* xW, const float* offW, const float* vq, const float* bias, const float* qc, float* h,
+                    int P, int N, int Q, int H, hipStream_t stream) {
+  hipLaunchKernelGGL(enc_combine_fwd_kernel, dim3(N, P, 3), dim3(128), 0, stream, xW, offW, vq, bias, qc, h, P, N, Q, H);
+  CRADLE_CHECK_LAUNCH("enc_combine_fwd_kernel");
+  return CRADLE_OK;
+}
+
+// dpre (3PN, H) -> doffW (2P*N, H), dxW (2N, H)
+__global__ __launch_bounds__(128) void enc_combine_bwd_kernel(const float* __restrict__ dpre, float* __restrict__ doffW,
+                                                              float* __restrict__ dxW, int P, int N, int H) {
+  const int n = blockIdx.x;
+  const int64_t PN = (int64_t)P * N;
+  for (int j = threadIdx.x; j < H; j += 128) {
+    float sa = 0.f, sb = 0.f;
+    for (int p = 0; p < P; ++p) {
+      const int64_t r = (int64_t)p * N + n;
+      const float a = dpre[r * H + j] + dpre[(PN + r) * H + j];
+      const float b = dpre[(2 * PN + r) * H + j];
+      doffW[r * H + j] = a;
+      doffW[(PN + r) * H + j] = b;
+      sa += a;
+      sb += b;
+    }
+    dxW[(int64_t)n * H + j] = sa;
+    dxW[(int64_t)(N + n) * H + j] = sb;
+  }
+}
+
+// dvq[pp,q,:] = sum_n s_q[n] dpre[variant rows]
+__global__ __launch_bounds__(128) void enc_combine_bwd_vq_kernel(const float* __restrict__ dpre, const float* __restrict__ qc,
+                                                                 float* __restrict__ dvq, int P, int N, int Q, int H) {
+  const int q = blockIdx.x, pp = blockIdx.y;
+  const int64_t PN = (int64_t)P * N;
+  for (int j = threadIdx.x; j < H; j += 128) {
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float s = qc[(int64_t)n * Q + q];
+      if (pp < P) {
+        const int64_t r = (int64_t)pp * N + n;
+        acc += s * dpre[r * H + j] + (1.0f - s) * dpre[(PN + r) * H + j];
+      } else {
+        const int64_t r = 2 * PN + (int64_t)(pp - P) * N + n;
+        acc += (1.0f - s) * dpre[r * H + j];
+      }
+    }
+    dvq[((int64_t)pp * Q + q) * H + j] = acc;
+  }
+}
+
+int enc_combine_bwd(const float* dpre, const float* qc, float* doffW, float* dxW, float* dvq, int P, int N, int Q, int H,
+                    hipStream_t stream) {
+  hipLaunchKernelGGL(enc_combine_bwd_kernel, dim3(N), dim3(128), 0, stream, dpre, doffW, dxW, P, N, H);
+  hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3(Q, 2 * P), dim3(128), 0, stream, dpre, qc, dvq, P, N, Q, H);
+  CRADLE_CHECK_LAUNCH("enc_combine_bwd");
+  return CRADLE_OK;
+}
+
+// =====================================================================================
+// small helpers
+// =====================================================================================
+// out[c, r] = W[r, col0 + c]: the one-hot block of the embedding encoder's first layer
+// (correlated_normal_guide.py:147-153) as a (T, H) table that the GEMM epilogue adds by row.
+__global__ __launch_bounds__(256) void transpose_cols_kernel(const float* __restrict__ W, int64_t ldw, int rows, int col0,
+                                                             int cols, float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? W[(int64_t)r * ldw + col0 + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) out[(int64_t)c * rows + r] = tile[tx][i];
+  }
+}
+
+int transpose_cols(const float* W, int64_t ldw, int rows, int col0, int cols, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(transpose_cols_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, stream, W, ldw, rows,
+                     col0, cols, out);
+  CRADLE_CHECK_LAUNCH("transpose_cols_kernel");
+  return CRADLE_OK;
+}
+
+// dW[h, col0 + t] = sum_groups da[g*T + t, h]   (gradient of the one-hot block)
+__global__ __launch_bounds__(256) void sum_groups_to_cols_kernel(const float* __restrict__ da, int groups, int T, int H,
+                                                                 float* __restrict__ dW, int64_t lddw, int col0) {
+  __shared__ float tile[32][33];
+  const int t0 = blockIdx.x * 32, h0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, h = h0 + tx;
+    float s = 0.f;
+    if (t < T && h < H)
+      for (int g = 0; g < groups; ++g) s += da[((int64_t)g * T + t) * H + h];
+    tile[i][tx] = s;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int h = h0 + i, t = t0 + tx;
+    if (h < H && t < T) dW[(int64_t)h * lddw + col0 + t] = tile[tx][i];
+  }
+}
+
+int sum_over_groups_to_cols(const float* da, int groups, int T, int H, float* dW, int64_t lddw, int col0,
+                            hipStream_t stream) {
+  hipLaunchKernelGGL(sum_groups_to_cols_kernel, dim3((T + 31) / 32, (H + 31) / 32), dim3(256), 0, stream, da, groups, T, H,
+                     dW, lddw, col0);
+  CRADLE_CHECK_LAUNCH("sum_groups_to_cols_kernel");
+  return CRADLE_OK;
+}
+
+// out[p, :] = sum_n w[n] da[p*N + n, :]   (gradient of the per-particle bad-variant shift)
+__global__ __launch_bounds__(128) void weighted_rowgroup_sum_kernel(const float* __restrict__ da, const float* __restrict__ w,
+                                                                    int N, int H, float* __restrict__ out) {
+  const int p = blockIdx.x;
+  for (int j = blockIdx.y * 128 + threadIdx.x; j < H; j += gridDim.y * 128) {
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc = fmaf(w[n], da[((int64_t)p * N + n) * H + j], acc);
+    out[(int64_t)p * H + j] = acc;
+  }
+}
+
+int weighted_rowgroup_sum(const float* da, const float* w, int P, int N, int H, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(weighted_rowgroup_sum_kernel, dim3(P, (H + 127) / 128), dim3(128), 0, stream, da, w, N, H, out);
+  CRADLE_CHECK_LAUNCH("weighted_rowgroup_sum_kernel");
+  return CRADLE_OK;
+}
+
+// loss_modules.py:179-185: loss = -mean_{p,n}(sum of terms) + beta*KL; metrics = -mean of each term.
+// out: [0] loss, [1] reconstruction, [2] mask, [3] E, [4] qc_E, [5] z_basal, [6] cf_KLdivergence
+__global__ __launch_bounds__(1024) void finalize_loss_kernel(const float* __restrict__ recon, const float* __restrict__ wrec,
+                                                             const float* __restrict__ ltz, const float* __restrict__ klrow,
+                                                             const float* __restrict__ Smask, const float* __restrict__ SE,
+                                                             const float* __restrict__ Sq, const float* __restrict__ cw,
+                                                             const float* __restrict__ cwq, float beta, int P, int N, int T,
+                                                             int Q, float* __restrict__ out) {
+  __shared__ float red[6][16];
+  float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int64_t PN = (int64_t)P * N;
+  for (int64_t r = threadIdx.x; r < PN; r += 1024) {
+    a[0] += wrec[r % N] * recon[r];
+    a[4] += ltz[r];
+    a[5] += klrow[r];
+  }
+  for (int r = threadIdx.x; r < P * T; r += 1024) {
+    a[1] += cw[r % T] * Smask[r];
+    a[2] += cw[r % T] * SE[r];
+  }
+  for (int r = threadIdx.x; r < P * Q; r += 1024) a[3] += cwq[r % Q] * Sq[r];
+  float tot[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) tot[k] = block_sum<1024>(a[k], red[k]);
+  if (threadIdx.x == 0) {
+    const float inv = 1.0f / (float)PN;
+    float loss = 0.f;
+    for (int k = 0; k < 5; ++k) {
+      out[1 + k] = -tot[k] * inv;
+      loss += out[1 + k];
+    }
+    const float kl = beta * tot[5] / (float)P;
+    out[6] = kl;
+    out[0] = loss + kl;
+  }
+}
+
+int finalize_loss(const float* recon, const float* wrec, const float* ltz, const float* klrow, const float* Smask,
+                  const float* SE, const float* Sq, const float* cw, const float* cwq, float beta, int P, int N, int T,
+                  int Q, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1024), 0, stream, recon, wrec, ltz, klrow, Smask, SE, Sq, cw, cwq,
+                     beta, P, N, T, Q, out);
+  CRADLE_CHECK_LAUNCH("finalize_loss_kernel");
+  return CRADLE_OK;
+}
+
+}  // namespace cradle

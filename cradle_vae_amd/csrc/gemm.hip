@@ -15,6 +15,7 @@
 // order inside a step is permuted identically for A and B, which a dot product allows.
 // 256 threads = 4 waves in a 2x2 arrangement; each wave owns TM x TN tiles of 32x32.
 #include "common.h"
+#include "kernels.h"
 
 namespace cradle {
 
@@ -22,36 +23,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;
 constexpr int KPAD = 4;  // K-major LDS row stride 20 floats: conflict-free ds_read_b128
-
-struct GemmParams {
-  const float* A;
-  const float* B;
-  float* C;
-  int64_t lda, ldb, ldc;
-  int M, N, K;
-  float beta;  // C = v + beta * C_old
-  // epilogue (all optional)
-  const float* bias;      // [N]
-  const float* rowbias;   // rowbias[rb_row * ld_rb + col], rb_row = row / rb_n (mode 1) or row % rb_n (mode 2)
-  int64_t ld_rb;
-  int rb_mode, rb_n;
-  const float* rowscale;  // multiplies the rowbias term, indexed by row % rs_n
-  int rs_n;
-  int act;                // 1: LeakyReLU(0.01)
-  float* act_out;         // store of the activation before the residual is added
-  int64_t ld_act;
-  const float* res;       // residual added after the activation
-  int64_t ld_res;
-  const float* dact_src;  // second output C2 = v * (dact_src > 0 ? 1 : 0.01)
-  int64_t ld_ds;
-  float* C2;
-  int64_t ldc2;
-  float* extra_col;       // TN only: B gets a virtual all-ones column N; its result goes here [M]
-  // split-K
-  int splitk;             // grid.z; >1: raw partial tiles to `partial` (z, M, Np), no epilogue
-  float* partial;
-  int k_tiles_per_split;
-};
 
 template <bool KMAJOR, int ROWS>
 struct TileLoader {

@@ -1,0 +1,480 @@
+// The fused ELBO step: forward + backward of PerturbationPlatedELBOLossModule.loss
+// (reference cradle_vae/models/utils/loss_modules.py:54-187) as one stream-ordered sequence of
+// hand-written kernels.  No autograd, no allocation, no host synchronisation: the caller hands
+// in parameter / gradient / batch / noise pointers and one workspace, and gets the loss terms
+// and every parameter gradient back.  Capturable into a HIP graph.
+//
+// Algebraic restructurings relative to the reference (i-vii; all exact up to
+// fp32 reassociation):
+//   (i)   x_good / x_bad are not sampled (model.py:131-132 draws are unused by the loss);
+//   (ii)  logstd(X) Wx^T and logstd(cfX) Wx^T are computed once, not once per particle and call;
+//   (iii) the counterfactual pass evaluates q_z_basal only (its q_z_cf_basal and z_basal draw are
+//         unused, loss_modules.py:146-150);
+//   (iv)  qc in {0,1}: only the live decoder variant of each cell is decoded and scored;
+//   (v)   the lgamma terms of the likelihood are evaluated per (cell, gene), not per particle;
+//   (vi)  the one-hot block of the embedding encoder's first layer is a table lookup;
+//   (vii) every matmul(D, .) / matmul(qc, .) is a gather / scatter over <= kmax non-zeros per cell.
+#include "common.h"
+#include "kernels.h"
+
+using namespace cradle;
+
+extern "C" {
+
+#define CRADLE_MAX_LAYERS 8
+
+// Pointers of one MLP: trunk layers (W[k]: (H, K_k) row-major, b[k]: (H)) and its output layer
+// (Gaussian heads stacked [mean_encoder; log_var_encoder] as (2L, H) / (2L), or the decoder's
+// normalized_mean_decoder (G, H) / (G)).  Used for parameters and, with the same shapes, gradients.
+struct cradle_mlp_ptrs {
+  int n_layers;
+  float* W[CRADLE_MAX_LAYERS];
+  float* b[CRADLE_MAX_LAYERS];
+  float* W_head;
+  float* b_head;
+};
+
+struct cradle_step_desc {
+  // sizes
+  int P, N, T, L, Q, G, He, Hm, Hd, kmax;
+  // parameters and their gradients (written, not accumulated)
+  float* q_mask_logits;       // (T, L)
+  float* d_q_mask_logits;
+  cradle_mlp_ptrs emb, d_emb;  // embedding encoder  (W[0]: (Hm, L+T))
+  cradle_mlp_ptrs qce, d_qce;  // qc encoder         (W[0]: (Hm, L))
+  cradle_mlp_ptrs enc, d_enc;  // basal encoder      (W[0]: (He, G+2L))
+  cradle_mlp_ptrs dec, d_dec;  // decoder            (W[0]: (Hd, 3L), head: (G, Hd))
+  float* log_concentration;   // (G)
+  float* d_log_concentration;
+  // buffers
+  const float* p_E_loc; const float* p_E_scale; const float* p_mask_probs;  // (T, L)
+  const float* p_qc_E_loc; const float* p_qc_E_scale;                        // (Q, L)
+  const float* log_mean; const float* log_scale;                             // (G)
+  float temperature;
+  // batch
+  const float* X; const float* cfX;  // (N, G)
+  const float* D;                    // (N, T)
+  const float* qc;                   // (N, Q)
+  const float* library_size;         // (N)
+  const float* D_obs_counts;         // (T)
+  const float* qc_obs_counts;        // (Q)
+  // noise: particles [0,P) main guide pass, [P,2P) counterfactual pass
+  const float* u_mask;    // (2P, T, L) uniforms
+  const float* eps_E;     // (2P, T, L)
+  const float* eps_qc_E;  // (2P, Q, L)
+  const float* eps_z;     // (P, N, L)
+  float beta;
+  float alpha;            // < 0: alpha = qc.sum()/N (loss_modules.py:137-139)
+  int compute_grads;      // 0: forward only (validation / test step)
+  // outputs
+  float* out;             // (8): loss, loss_term_{reconstruction,mask,E,qc_E,z_basal}, cf_KLdivergence, -
+  int* flags;             // (1): bit 0 = more than kmax dosages in a cell, bit 1 = qc not binary
+  // scratch
+  void* workspace;
+  int64_t workspace_bytes;
+};
+
+}  // extern "C"
+
+namespace {
+
+struct Arena {
+  char* base;
+  int64_t off = 0;
+  explicit Arena(void* b) : base(reinterpret_cast<char*>(b)) {}
+  template <typename T>
+  T* take(int64_t count) {
+    off = (off + 255) & ~int64_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * (int64_t)sizeof(T);
+    return p;
+  }
+};
+
+constexpr int64_t kSplitKFloats = 8ll << 20;
+
+struct Work {
+  DosagePlan plan;
+  CellPrep cp;
+  float *hascf, *gene_consts;
+  float *mask, *soft, *Smask, *W0tT;
+  float *yE[CRADLE_MAX_LAYERS], *rE[CRADLE_MAX_LAYERS], *headsE, *sdE, *E, *ME, *SE;
+  float *yq[CRADLE_MAX_LAYERS], *rq[CRADLE_MAX_LAYERS], *headsq, *sdq, *qcE, *Sq, *qsum, *ones_q;
+  float *xn, *xW, *offB, *zoff, *offW, *vq;
+  float *yz[CRADLE_MAX_LAYERS], *rz[CRADLE_MAX_LAYERS], *headsz, *sdz, *ltz, *klrow;
+  float *wq, *yd[CRADLE_MAX_LAYERS], *rd[CRADLE_MAX_LAYERS], *logits, *recon, *nbws;
+  // backward
+  float *Gd[2], *dad[2], *dzoff, *dwq, *dq_dec;
+  float *dheadsz, *Gz[2], *daz[2], *doffW, *dxW, *dvq, *doffenc, *dq_enc;
+  float *dME, *dmaskME, *dheadsE, *GE[2], *daE[2], *dmask_enc;
+  float *dheadsq, *Gq[2], *daq[2];
+  float* splitk;
+  int64_t nbws_floats;
+};
+
+int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
+  Arena a(base);
+  const int P = d.P, N = d.N, T = d.T, L = d.L, Q = d.Q, G = d.G, He = d.He, Hm = d.Hm, Hd = d.Hd;
+  const int PP = 2 * P;
+  const int64_t PN = (int64_t)P * N, PT = (int64_t)PP * T;
+  w.plan.kmax = d.kmax;
+  w.plan.ell_idx = a.take<int>((int64_t)N * d.kmax);
+  w.plan.ell_val = a.take<float>((int64_t)N * d.kmax);
+  w.plan.tcount = a.take<int>(T);
+  w.plan.tstart = a.take<int>(T + 1);
+  w.plan.csc_cell = a.take<int>((int64_t)N * d.kmax);
+  w.plan.csc_val = a.take<float>((int64_t)N * d.kmax);
+  w.plan.flags = d.flags;
+  w.cp.alpha = a.take<float>(1);
+  w.cp.live = a.take<float>(N);
+  w.cp.wrec = a.take<float>(N);
+  w.cp.grow = a.take<float>(PN);
+  w.cp.cw = a.take<float>(T);
+  w.cp.cwq = a.take<float>(Q);
+  w.cp.coefT = a.take<float>(T);
+  w.cp.coefQ = a.take<float>(Q);
+  w.hascf = a.take<float>(N);
+  w.gene_consts = a.take<float>(3ll * G);
+  w.mask = a.take<float>(PT * L);
+  w.soft = a.take<float>(PT * L);
+  w.Smask = a.take<float>(PT);
+  w.W0tT = a.take<float>((int64_t)T * Hm);
+  for (int k = 0; k < d.emb.n_layers; ++k) {
+    w.yE[k] = a.take<float>(PT * Hm);
+    w.rE[k] = k ? a.take<float>(PT * Hm) : nullptr;
+  }
+  w.headsE = a.take<float>(PT * 2 * L);
+  w.sdE = a.take<float>(PT * L);
+  w.E = a.take<float>(PT * L);
+  w.ME = a.take<float>(PT * L);
+  w.SE = a.take<float>(PT);
+  for (int k = 0; k < d.qce.n_layers; ++k) {
+    w.yq[k] = a.take<float>((int64_t)Q * Hm);
+    w.rq[k] = k ? a.take<float>((int64_t)Q * Hm) : nullptr;
+  }
+  w.headsq = a.take<float>((int64_t)Q * 2 * L);
+  w.sdq = a.take<float>((int64_t)Q * L);
+  w.qcE = a.take<float>((int64_t)PP * Q * L);
+  w.Sq = a.take<float>((int64_t)PP * Q);
+  w.qsum = a.take<float>((int64_t)P * L);
+  w.ones_q = a.take<float>((int64_t)Q * L);
+  w.xn = a.take<float>(2ll * N * G);
+  w.xW = a.take<float>(2ll * N * He);
+  w.offB = a.take<float>(PN * L);
+  w.zoff = a.take<float>(PN * 2 * L);
+  w.offW = a.take<float>(2 * PN * He);
+  w.vq = a.take<float>((int64_t)PP * Q * He);
+  for (int k = 0; k < d.enc.n_layers; ++k) {
+    w.yz[k] = a.take<float>(3 * PN * He);
+    w.rz[k] = k ? a.take<float>(3 * PN * He) : nullptr;
+  }
+  w.headsz = a.take<float>(3 * PN * 2 * L);
+  w.sdz = a.take<float>(PN * L);
+  w.ltz = a.take<float>(PN);
+  w.klrow = a.take<float>(PN);
+  w.wq = a.take<float>((int64_t)P * Hd);
+  for (int k = 0; k < d.dec.n_layers; ++k) {
+    w.yd[k] = a.take<float>(PN * Hd);
+    w.rd[k] = k ? a.take<float>(PN * Hd) : nullptr;
+  }
+  w.logits = a.take<float>(PN * G);
+  w.recon = a.take<float>(PN);
+  w.nbws_floats = cradle_nb_workspace_floats(P, N, G);
+  w.nbws = a.take<float>(w.nbws_floats);
+  for (int i = 0; i < 2; ++i) {
+    w.Gd[i] = a.take<float>(PN * Hd);
+    w.dad[i] = a.take<float>(PN * Hd);
+    w.Gz[i] = a.take<float>(3 * PN * He);
+    w.daz[i] = a.take<float>(3 * PN * He);
+    w.GE[i] = a.take<float>(PT * Hm);
+    w.daE[i] = a.take<float>(PT * Hm);
+    w.Gq[i] = a.take<float>((int64_t)Q * Hm);
+    w.daq[i] = a.take<float>((int64_t)Q * Hm);
+  }
+  w.dzoff = a.take<float>(PN * 2 * L);
+  w.dwq = a.take<float>((int64_t)P * Hd);
+  w.dq_dec = a.take<float>((int64_t)P * L);
+  w.dheadsz = a.take<float>(3 * PN * 2 * L);
+  w.doffW = a.take<float>(2 * PN * He);
+  w.dxW = a.take<float>(2ll * N * He);
+  w.dvq = a.take<float>((int64_t)PP * Q * He);
+  w.doffenc = a.take<float>(2 * PN * L);
+  w.dq_enc = a.take<float>((int64_t)PP * Q * L);
+  w.dME = a.take<float>(PT * L);
+  w.dmaskME = a.take<float>(PT * L);
+  w.dheadsE = a.take<float>(PT * 2 * L);
+  w.dmask_enc = a.take<float>(PT * L);
+  w.dheadsq = a.take<float>((int64_t)Q * 2 * L);
+  w.splitk = a.take<float>(kSplitKFloats);
+  return (a.off + 255) & ~int64_t(255);
+}
+
+struct Ctx {
+  hipStream_t s;
+  float* splitk;
+  int rc = 0;
+  // C[M,N] = A . B(^T) with epilogue options set by the caller in p
+  void gemm(int layout, GemmParams p) {
+    if (rc) return;
+    rc = gemm_f32(layout, p, splitk, kSplitKFloats, s);
+  }
+};
+
+GemmParams gp(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K) {
+  GemmParams p = {};
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  return p;
+}
+
+// Layers 1..n-1 of a ResidualMLP (mlp.py:111-119): y_k = LeakyReLU(y_{k-1} W_k^T + b_k) + y_{k-1}.
+void trunk_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, float* const* y, float* const* r) {
+  for (int k = 1; k < m.n_layers; ++k) {
+    GemmParams p = gp(y[k - 1], H, m.W[k], H, y[k], H, M, H, H);
+    p.bias = m.b[k]; p.act = 1; p.act_out = r[k]; p.ld_act = H; p.res = y[k - 1]; p.ld_res = H;
+    c.gemm(GEMM_NT, p);
+  }
+}
+
+// Output layer forward: out = y_last W_head^T + b_head.
+void head_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, int Nout, const float* ylast, float* out) {
+  GemmParams p = gp(ylast, H, m.W_head, H, out, Nout, M, Nout, H);
+  p.bias = m.b_head;
+  c.gemm(GEMM_NT, p);
+}
+
+// Backward through the output layer and trunk layers n-1..1.  dout: (M, Nout) gradient of the
+// output layer's result.  Writes dW_head, db_head, dW[k], db[k] (k >= 1) and returns da_0 =
+// dL/d(pre-activation of layer 0) in (M, H).
+const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, int M, int H, int Nout,
+                            const float* dout, float* const* y, float* const* r, float* const* Gb, float* const* dab) {
+  const int n = m.n_layers;
+  {  // dW_head = dout^T y_last, db_head = colsum(dout)
+    GemmParams p = gp(dout, Nout, y[n - 1], H, g.W_head, H, Nout, H, M);
+    p.extra_col = g.b_head;
+    c.gemm(GEMM_TN, p);
+  }
+  int cur = 0;
+  {  // G_{n-1} = dout W_head ; da_{n-1} = G_{n-1} * slope(r_{n-1})
+    GemmParams p = gp(dout, Nout, m.W_head, H, Gb[cur], H, M, H, Nout);
+    p.dact_src = n > 1 ? r[n - 1] : y[0]; p.ld_ds = H; p.C2 = dab[cur]; p.ldc2 = H;
+    c.gemm(GEMM_NN, p);
+  }
+  for (int k = n - 1; k >= 1; --k) {
+    {  // dW_k = da_k^T y_{k-1}
+      GemmParams p = gp(dab[cur], H, y[k - 1], H, g.W[k], H, H, H, M);
+      p.extra_col = g.b[k];
+      c.gemm(GEMM_TN, p);
+    }
+    {  // G_{k-1} = da_k W_k + G_k ; da_{k-1} = G_{k-1} * slope(r_{k-1})   (r_0 = y_0)
+      GemmParams p = gp(dab[cur], H, m.W[k], H, Gb[cur ^ 1], H, M, H, H);
+      p.res = Gb[cur]; p.ld_res = H;
+      p.dact_src = k - 1 >= 1 ? r[k - 1] : y[0]; p.ld_ds = H; p.C2 = dab[cur ^ 1]; p.ldc2 = H;
+      c.gemm(GEMM_NN, p);
+    }
+    cur ^= 1;
+  }
+  return dab[cur];
+}
+
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+int check_desc(const cradle_step_desc& d) {
+  CRADLE_CHECK_ARG(d.P > 0 && d.N > 0 && d.T > 0 && d.L > 0 && d.Q > 0 && d.G > 0 && d.He > 0 && d.Hm > 0 && d.Hd > 0,
+                   "elbo_step: all sizes must be positive");
+  CRADLE_CHECK_ARG(d.G % 4 == 0, "elbo_step: n_phenos=%d must be a multiple of 4", d.G);
+  CRADLE_CHECK_ARG(d.kmax >= 1 && d.kmax <= 64, "elbo_step: kmax=%d out of range [1,64]", d.kmax);
+  const cradle_mlp_ptrs* ms[4] = {&d.emb, &d.qce, &d.enc, &d.dec};
+  const cradle_mlp_ptrs* gs[4] = {&d.d_emb, &d.d_qce, &d.d_enc, &d.d_dec};
+  for (int i = 0; i < 4; ++i) {
+    CRADLE_CHECK_ARG(ms[i]->n_layers >= 1 && ms[i]->n_layers <= CRADLE_MAX_LAYERS, "elbo_step: mlp %d has %d layers", i,
+                     ms[i]->n_layers);
+    CRADLE_CHECK_ARG(ms[i]->W_head && ms[i]->b_head, "elbo_step: mlp %d has a null output layer", i);
+    for (int k = 0; k < ms[i]->n_layers; ++k) {
+      CRADLE_CHECK_ARG(ms[i]->W[k] && ms[i]->b[k], "elbo_step: mlp %d layer %d is null", i, k);
+      CRADLE_CHECK_ARG(!d.compute_grads || (gs[i]->W[k] && gs[i]->b[k] && gs[i]->W_head && gs[i]->b_head),
+                       "elbo_step: gradient pointers of mlp %d layer %d are null", i, k);
+    }
+  }
+  CRADLE_CHECK_ARG(d.q_mask_logits && d.log_concentration && d.p_E_loc && d.p_E_scale && d.p_mask_probs &&
+                       d.p_qc_E_loc && d.p_qc_E_scale && d.log_mean && d.log_scale,
+                   "elbo_step: null parameter/buffer pointer");
+  CRADLE_CHECK_ARG(!d.compute_grads || (d.d_q_mask_logits && d.d_log_concentration), "elbo_step: null gradient pointer");
+  CRADLE_CHECK_ARG(d.X && d.cfX && d.D && d.qc && d.library_size && d.D_obs_counts && d.qc_obs_counts,
+                   "elbo_step: null batch pointer");
+  CRADLE_CHECK_ARG(d.u_mask && d.eps_E && d.eps_qc_E && d.eps_z, "elbo_step: null noise pointer");
+  CRADLE_CHECK_ARG(d.out && d.flags && d.workspace, "elbo_step: null output/workspace pointer");
+  CRADLE_CHECK_ARG((uintptr_t)d.workspace % 256 == 0, "elbo_step: workspace must be 256-byte aligned");
+  CRADLE_CHECK_ARG((uintptr_t)d.X % 16 == 0, "elbo_step: X must be 16-byte aligned");
+  CRADLE_CHECK_ARG(d.temperature > 0.f, "elbo_step: temperature must be positive");
+  return CRADLE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* d) {
+  if (!d) return -1;
+  Work w;
+  return carve(*d, nullptr, w);
+}
+
+int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
+  CRADLE_CHECK_ARG(dp, "elbo_step: null descriptor");
+  const cradle_step_desc& d = *dp;
+  int rc = check_desc(d);
+  if (rc) return rc;
+  Work w;
+  const int64_t need = carve(d, d.workspace, w);
+  CRADLE_CHECK_ARG(d.workspace_bytes >= need, "elbo_step: workspace has %lld bytes, needs %lld",
+                   (long long)d.workspace_bytes, (long long)need);
+  const int P = d.P, N = d.N, T = d.T, L = d.L, Q = d.Q, G = d.G, He = d.He, Hm = d.Hm, Hd = d.Hd;
+  const int PP = 2 * P, PN = P * N, PT = PP * T;
+  Ctx c{s, w.splitk};
+#define STEP(call)        \
+  do {                    \
+    rc = (call);          \
+    if (rc) return rc;    \
+  } while (0)
+
+  // ------------------------------------------------------------------ preparation
+  STEP(build_dosage_plan(d.D, N, T, w.plan, s));
+  STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, s));
+  STEP(cradle_nb_gene_consts(d.log_concentration, w.gene_consts, G, s));
+  STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s));
+
+  // ------------------------------------------------------------------ q(M), q(E|M): both guide passes at once
+  STEP(mask_fwd(d.q_mask_logits, d.u_mask, d.p_mask_probs, d.temperature, w.mask, w.soft, w.Smask, PP, T, L, s));
+  STEP(transpose_cols(d.emb.W[0], L + T, Hm, L, T, w.W0tT, s));
+  {  // layer 0: LeakyReLU(mask Wm^T + W_onehot[:, t] + b)
+    GemmParams p = gp(w.mask, L, d.emb.W[0], L + T, w.yE[0], Hm, PT, Hm, L);
+    p.bias = d.emb.b[0]; p.act = 1; p.rowbias = w.W0tT; p.ld_rb = Hm; p.rb_mode = 2; p.rb_n = T;
+    c.gemm(GEMM_NT, p);
+  }
+  trunk_fwd(c, d.emb, PT, Hm, w.yE, w.rE);
+  head_fwd(c, d.emb, PT, Hm, 2 * L, w.yE[d.emb.n_layers - 1], w.headsE);
+  if (c.rc) return c.rc;
+  STEP(gaussE_fwd(w.headsE, d.eps_E, w.mask, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.ME, w.SE, PP, T, L, s));
+
+  // ------------------------------------------------------------------ q(qc_E): constant input ones(Q, L)
+  hipLaunchKernelGGL(fill_kernel, dim3((Q * L + 255) / 256), dim3(256), 0, s, w.ones_q, (int64_t)Q * L, 1.0f);
+  {
+    GemmParams p = gp(w.ones_q, L, d.qce.W[0], L, w.yq[0], Hm, Q, Hm, L);
+    p.bias = d.qce.b[0]; p.act = 1;
+    c.gemm(GEMM_NT, p);
+  }
+  trunk_fwd(c, d.qce, Q, Hm, w.yq, w.rq);
+  head_fwd(c, d.qce, Q, Hm, 2 * L, w.yq[d.qce.n_layers - 1], w.headsq);
+  if (c.rc) return c.rc;
+  STEP(qce_fwd(w.headsq, d.eps_qc_E, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.Sq, w.qsum, PP, P, Q, L, s));
+
+  // ------------------------------------------------------------------ basal encoder
+  const float* Wenc0 = d.enc.W[0];
+  const int64_t ldenc = (int64_t)G + 2 * L;
+  c.gemm(GEMM_NT, gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G));                      // x Wx^T, X and cfX
+  STEP(gather_offsets(w.ME, w.plan, w.zoff + L, 2 * L, w.offB, L, PP, P, N, T, L, s));     // D @ (mask*E)
+  c.gemm(GEMM_NT, gp(w.zoff + L, 2 * L, Wenc0 + G, ldenc, w.offW, He, PN, He, L));         // main pass offsets
+  c.gemm(GEMM_NT, gp(w.offB, L, Wenc0 + G, ldenc, w.offW + (int64_t)PN * He, He, PN, He, L));  // cf pass offsets
+  c.gemm(GEMM_NT, gp(w.qcE, L, Wenc0 + G + L, ldenc, w.vq, He, PP * Q, He, L));            // qc_E Wqc^T
+  if (c.rc) return c.rc;
+  STEP(enc_combine_fwd(w.xW, w.offW, w.vq, d.enc.b[0], d.qc, w.yz[0], P, N, Q, He, s));
+  trunk_fwd(c, d.enc, 3 * PN, He, w.yz, w.rz);
+  head_fwd(c, d.enc, 3 * PN, He, 2 * L, w.yz[d.enc.n_layers - 1], w.headsz);
+  if (c.rc) return c.rc;
+  STEP(zhead_fwd(w.headsz, d.eps_z, w.hascf, d.beta, w.zoff, 2 * L, w.sdz, w.ltz, w.klrow, w.dheadsz, P, N, L, s));
+
+  // ------------------------------------------------------------------ decoder, live variant per cell
+  const float* Wd0 = d.dec.W[0];
+  c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L));  // bad-variant shift per particle
+  {
+    GemmParams p = gp(w.zoff, 2 * L, Wd0, 3 * L, w.yd[0], Hd, PN, Hd, 2 * L);
+    p.bias = d.dec.b[0]; p.act = 1; p.rowbias = w.wq; p.ld_rb = Hd; p.rb_mode = 1; p.rb_n = N;
+    p.rowscale = w.cp.live; p.rs_n = N;
+    c.gemm(GEMM_NT, p);
+  }
+  trunk_fwd(c, d.dec, PN, Hd, w.yd, w.rd);
+  head_fwd(c, d.dec, PN, Hd, G, w.yd[d.dec.n_layers - 1], w.logits);
+  if (c.rc) return c.rc;
+  if (!d.compute_grads) {
+    STEP(cradle_nb_logprob_fwd(w.logits, G, d.X, G, d.library_size, w.gene_consts, w.recon, P, N, G, s));
+  } else {
+    STEP(cradle_nb_logprob_fwd_bwd(w.logits, G, w.logits, G, d.X, G, d.library_size, w.gene_consts, w.cp.grow, w.recon,
+                                   d.d_log_concentration, 0, w.nbws, w.nbws_floats, P, N, G, s));
+  }
+  STEP(finalize_loss(w.recon, w.cp.wrec, w.ltz, w.klrow, w.Smask, w.SE, w.Sq, w.cp.cw, w.cp.cwq, d.beta, P, N, T, Q,
+                     d.out, s));
+  if (!d.compute_grads) return CRADLE_OK;
+
+  // ================================================================== backward
+  // decoder: logits now hold d loss / d logits
+  const float* da0d = head_trunk_bwd(c, d.dec, d.d_dec, PN, Hd, G, w.logits, w.yd, w.rd, w.Gd, w.dad);
+  if (c.rc) return c.rc;
+  {  // dW0[:, :2L] = da0^T [z | off], db0
+    GemmParams p = gp(da0d, Hd, w.zoff, 2 * L, d.d_dec.W[0], 3 * L, Hd, 2 * L, PN);
+    p.extra_col = d.d_dec.b[0];
+    c.gemm(GEMM_TN, p);
+  }
+  STEP(weighted_rowgroup_sum(da0d, w.cp.live, P, N, Hd, w.dwq, s));
+  c.gemm(GEMM_TN, gp(w.dwq, Hd, w.qsum, L, d.d_dec.W[0] + 2 * L, 3 * L, Hd, L, P));   // dW0[:, 2L:]
+  c.gemm(GEMM_NN, gp(w.dwq, Hd, Wd0 + 2 * L, 3 * L, w.dq_dec, L, P, L, Hd));          // d qsum
+  c.gemm(GEMM_NN, gp(da0d, Hd, Wd0, 3 * L, w.dzoff, 2 * L, PN, 2 * L, Hd));           // [dz | doff]
+  if (c.rc) return c.rc;
+
+  // basal encoder
+  STEP(zhead_bwd(w.headsz, d.eps_z, w.zoff, 2 * L, w.sdz, w.dzoff, 2 * L, w.dheadsz, P, N, L, s));
+  const float* dpre = head_trunk_bwd(c, d.enc, d.d_enc, 3 * PN, He, 2 * L, w.dheadsz, w.yz, w.rz, w.Gz, w.daz);
+  if (c.rc) return c.rc;
+  STEP(enc_combine_bwd(dpre, d.qc, w.doffW, w.dxW, w.dvq, P, N, Q, He, s));
+  float* dWenc0 = d.d_enc.W[0];
+  {  // dWx = dxW^T logstd([X; cfX]); db0 = colsum(dxW)
+    GemmParams p = gp(w.dxW, He, w.xn, G, dWenc0, ldenc, He, G, 2 * N);
+    p.extra_col = d.d_enc.b[0];
+    c.gemm(GEMM_TN, p);
+  }
+  // dWoff = doffW^T [offA; offB]  (two row blocks of one sum: second call accumulates)
+  c.gemm(GEMM_TN, gp(w.doffW, He, w.zoff + L, 2 * L, dWenc0 + G, ldenc, He, L, PN));
+  {
+    GemmParams p = gp(w.doffW + (int64_t)PN * He, He, w.offB, L, dWenc0 + G, ldenc, He, L, PN);
+    p.beta = 1.0f;
+    c.gemm(GEMM_TN, p);
+  }
+  c.gemm(GEMM_TN, gp(w.dvq, He, w.qcE, L, dWenc0 + G + L, ldenc, He, L, PP * Q));      // dWqc
+  c.gemm(GEMM_NN, gp(w.doffW, He, Wenc0 + G, ldenc, w.doffenc, L, 2 * PN, L, He));     // d offsets via encoder
+  c.gemm(GEMM_NN, gp(w.dvq, He, Wenc0 + G + L, ldenc, w.dq_enc, L, PP * Q, L, He));    // d qc_E via encoder
+  if (c.rc) return c.rc;
+
+  // q(qc_E)
+  STEP(qce_bwd(w.headsq, d.eps_qc_E, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.dq_enc, w.dq_dec, w.cp.coefQ,
+               w.dheadsq, PP, P, Q, L, s));
+  const float* da0q = head_trunk_bwd(c, d.qce, d.d_qce, Q, Hm, 2 * L, w.dheadsq, w.yq, w.rq, w.Gq, w.daq);
+  {
+    GemmParams p = gp(da0q, Hm, w.ones_q, L, d.d_qce.W[0], L, Hm, L, Q);
+    p.extra_col = d.d_qce.b[0];
+    c.gemm(GEMM_TN, p);
+  }
+  if (c.rc) return c.rc;
+
+  // q(E|M), q(M)
+  STEP(scatter_offsets(w.plan, w.dzoff + L, 2 * L, w.doffenc, L, w.doffenc + (int64_t)PN * L, L, w.dME, PP, P, N, T, L, s));
+  STEP(gaussE_bwd(w.headsE, d.eps_E, w.mask, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.dME, w.cp.coefT, w.dheadsE, w.dmaskME,
+                  PP, P, T, L, s));
+  const float* da0E = head_trunk_bwd(c, d.emb, d.d_emb, PT, Hm, 2 * L, w.dheadsE, w.yE, w.rE, w.GE, w.daE);
+  if (c.rc) return c.rc;
+  {  // dW0[:, :L] = da0^T mask, db0
+    GemmParams p = gp(da0E, Hm, w.mask, L, d.d_emb.W[0], L + T, Hm, L, PT);
+    p.extra_col = d.d_emb.b[0];
+    c.gemm(GEMM_TN, p);
+  }
+  STEP(sum_over_groups_to_cols(da0E, PP, T, Hm, d.d_emb.W[0], L + T, L, s));            // dW0[:, L:]
+  c.gemm(GEMM_NN, gp(da0E, Hm, d.emb.W[0], L + T, w.dmask_enc, L, PT, L, Hm));           // d mask via encoder input
+  if (c.rc) return c.rc;
+  STEP(mask_bwd(d.q_mask_logits, d.p_mask_probs, d.temperature, w.mask, w.soft, w.dmaskME, w.dmask_enc, w.cp.coefT,
+                d.d_q_mask_logits, PP, P, T, L, s));
+#undef STEP
+  return CRADLE_OK;
+}
+
+}  // extern "C"

@@ -34,7 +34,48 @@ PROTOTYPES = {
     "cradle_nb_particle_split": (i32, [i32, i32]),
     "cradle_gemm_f32": (i32, [ctypes.c_void_p, c_float_p, i64, c_stream]),
     "cradle_gemm_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
+    "cradle_elbo_step_workspace_bytes": (i64, [ctypes.c_void_p]),
+    "cradle_elbo_step": (i32, [ctypes.c_void_p, c_stream]),
+    "cradle_adam_step": (
+        i32,
+        [c_float_p, c_float_p, c_float_p, c_float_p, i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+         ctypes.c_float, ctypes.c_float, i32, ctypes.c_float, ctypes.c_float, c_float_p, c_stream],
+    ),
+    "cradle_adam_workspace_floats": (i64, []),
 }
+
+MAX_LAYERS = 8
+
+
+class MlpPtrs(ctypes.Structure):
+    """struct cradle_mlp_ptrs."""
+
+    _fields_ = [
+        ("n_layers", i32),
+        ("W", ctypes.c_void_p * MAX_LAYERS),
+        ("b", ctypes.c_void_p * MAX_LAYERS),
+        ("W_head", ctypes.c_void_p),
+        ("b_head", ctypes.c_void_p),
+    ]
+
+
+class StepDesc(ctypes.Structure):
+    """struct cradle_step_desc (include/cradle_hip.h); field order is ABI."""
+
+    _fields_ = (
+        [(k, i32) for k in ("P", "N", "T", "L", "Q", "G", "He", "Hm", "Hd", "kmax")]
+        + [("q_mask_logits", ctypes.c_void_p), ("d_q_mask_logits", ctypes.c_void_p)]
+        + [(k, MlpPtrs) for k in ("emb", "d_emb", "qce", "d_qce", "enc", "d_enc", "dec", "d_dec")]
+        + [("log_concentration", ctypes.c_void_p), ("d_log_concentration", ctypes.c_void_p)]
+        + [(k, ctypes.c_void_p) for k in ("p_E_loc", "p_E_scale", "p_mask_probs", "p_qc_E_loc", "p_qc_E_scale",
+                                          "log_mean", "log_scale")]
+        + [("temperature", ctypes.c_float)]
+        + [(k, ctypes.c_void_p) for k in ("X", "cfX", "D", "qc", "library_size", "D_obs_counts", "qc_obs_counts",
+                                          "u_mask", "eps_E", "eps_qc_E", "eps_z")]
+        + [("beta", ctypes.c_float), ("alpha", ctypes.c_float), ("compute_grads", i32)]
+        + [("out", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+           ("workspace_bytes", i64)]
+    )
 
 
 class GemmDesc(ctypes.Structure):

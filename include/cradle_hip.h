@@ -105,6 +105,74 @@ typedef struct cradle_gemm_desc {
 int cradle_gemm_f32(const cradle_gemm_desc* desc, float* workspace, int64_t workspace_floats, cradle_stream_t stream);
 int64_t cradle_gemm_workspace_floats(int layout, int M, int N, int K, int extra_col);
 
+/* ---- The fused ELBO step ---------------------------------------------------------------
+ * Forward + backward of PerturbationPlatedELBOLossModule.loss
+ * (cradle_vae/models/utils/loss_modules.py:54-187: guide(X,qc) -> model -> guide(cfX,1-qc),
+ * NB reconstruction with qc/alpha mixing :134-143, counterfactual KL :145-151,190-196, plated
+ * log-ratio terms :153-177,200-232, loss :179-181) including everything it calls:
+ * correlated_normal_guide.py:102-209, model.py:59-129, mlp.py:111-168, normalization.py:41-45,
+ * gumbel_softmax_bernoulli.py:5-17 -- and of the autograd backward Lightning runs after it.
+ * One stream-ordered sequence of kernels; nothing allocates or synchronises.
+ * Restrictions (every shipped config satisfies them): sum_mode=False, mean_field_encoder=False,
+ * log_standardize input normalisation, library_nb likelihood, qc entries in {0,1}, at most
+ * `kmax` non-zero dosages per cell.  Violations of the last two raise bits in *flags. */
+#define CRADLE_MAX_LAYERS 8
+typedef struct cradle_mlp_ptrs {
+  int n_layers;                 /* trunk layers, mlp.py:58 */
+  float* W[CRADLE_MAX_LAYERS];  /* W[k]: (H, K_k) row-major = mlp.layers.{k}.0.weight */
+  float* b[CRADLE_MAX_LAYERS];  /* (H) */
+  float* W_head;                /* [mean_encoder.weight; log_var_encoder.weight] (2L, H), or
+                                   normalized_mean_decoder.0.weight (G, H) for the decoder */
+  float* b_head;
+} cradle_mlp_ptrs;
+
+typedef struct cradle_step_desc {
+  int P, N, T, L, Q, G, He, Hm, Hd, kmax;
+  float* q_mask_logits;         /* (T, L) guide.param_dict.q_mask_logits */
+  float* d_q_mask_logits;
+  cradle_mlp_ptrs emb, d_emb;   /* guide.embedding_encoder, W[0]: (Hm, L+T) */
+  cradle_mlp_ptrs qce, d_qce;   /* guide.qc_encoder,        W[0]: (Hm, L)   */
+  cradle_mlp_ptrs enc, d_enc;   /* guide.z_basal_encoder,   W[0]: (He, G+2L) */
+  cradle_mlp_ptrs dec, d_dec;   /* model.decoder,           W[0]: (Hd, 3L), head (G, Hd) */
+  float* log_concentration;     /* (G) */
+  float* d_log_concentration;
+  const float* p_E_loc; const float* p_E_scale; const float* p_mask_probs;   /* (T, L) model.py:33-39 */
+  const float* p_qc_E_loc; const float* p_qc_E_scale;                         /* (Q, L) model.py:41-44 */
+  const float* log_mean; const float* log_scale;                              /* (G) normalization.py:38-39 */
+  float temperature;            /* guide.gs_temperature */
+  const float* X; const float* cfX;   /* (N, G) */
+  const float* D;                     /* (N, T) */
+  const float* qc;                    /* (N, Q) */
+  const float* library_size;          /* (N) */
+  const float* D_obs_counts;          /* (T) */
+  const float* qc_obs_counts;         /* (Q) */
+  const float* u_mask;    /* (2P, T, L) uniforms: particles [0,P) main guide pass, [P,2P) counterfactual pass */
+  const float* eps_E;     /* (2P, T, L) standard normals */
+  const float* eps_qc_E;  /* (2P, Q, L) */
+  const float* eps_z;     /* (P, N, L) */
+  float beta;
+  float alpha;            /* < 0: alpha = qc.sum()/N (loss_modules.py:137-139) */
+  int compute_grads;      /* 0: forward only */
+  float* out;             /* (8): loss, loss_term_{reconstruction,mask,E,qc_E,z_basal}, cf_KLdivergence, unused */
+  int* flags;             /* (1) */
+  void* workspace;
+  int64_t workspace_bytes;
+} cradle_step_desc;
+
+int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only the sizes are read */
+int cradle_elbo_step(const cradle_step_desc* desc, cradle_stream_t stream);
+
+/* ---- K10: gradient-norm clip + Adam over flat arenas -----------------------------------
+ * Replaces Lightning's gradient_clip_val (train_norman.py:96; torch clip_grad_norm_) followed by
+ * torch.optim.Adam(lr, weight_decay) (perturbation_lightning_module.py:147-150).
+ * g' = grads * grad_scale; coef = max_norm > 0 ? min(1, max_norm / (|g'| + 1e-6)) : 1;
+ * then Adam with L2 weight decay on g' * coef.  norm_ws: cradle_adam_workspace_floats() floats;
+ * its last element receives |g'|. */
+int cradle_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
+                     float grad_scale, float* norm_ws, cradle_stream_t stream);
+int64_t cradle_adam_workspace_floats(void);
+
 #ifdef __cplusplus
 }
 #endif
