@@ -150,6 +150,8 @@ def main():
         dist.barrier()
     ops.KERNEL_TIMERS.clear()
     ops.KERNEL_TIMING = True
+    if stepper.fused is not None:
+        stepper.fused.k1_events = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -170,6 +172,8 @@ def main():
         # ---- roofline of K1 from the HIP events recorded around its launches in the timed region
         P, N, G = shape.n_particles, shape.n_cells, shape.n_phenos
         k1 = [s.elapsed_time(e) * 1e-3 for (name, s, e) in ops.KERNEL_TIMERS if name == "nb_logprob_fwd_bwd"]
+        if stepper.fused is not None:  # events recorded by the C step around its K1 launches
+            k1 = [ev.elapsed_ms() * 1e-3 for ev in stepper.fused.k1_events]
         V = stepper.decoder_variants  # decoder variants scored per cell (2 = as the reference, 1 = live variant only)
         alg_bytes = 4.0 * G * (3 * P * N + 2 * N)  # SURVEY 8(d) per launch of one variant: fwd+bwd
         roofline = None

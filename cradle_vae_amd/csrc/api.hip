@@ -27,4 +27,26 @@ int cradle_device_count(void) {
   return n;
 }
 
+// HIP-event helpers for callers without a HIP binding of their own (bench.py times single
+// kernels of the fused step with them; see cradle_step_desc.ev_k1_begin/end).
+int cradle_event_create(void** ev) {
+  hipEvent_t e;
+  if (!ev || hipEventCreate(&e) != hipSuccess) {
+    cradle_set_error("event_create failed");
+    return CRADLE_ERR_HIP;
+  }
+  *ev = (void*)e;
+  return CRADLE_OK;
+}
+int cradle_event_destroy(void* ev) { return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? CRADLE_OK : CRADLE_ERR_HIP; }
+// elapsed milliseconds between two recorded events; both must have completed
+int cradle_event_elapsed_ms(void* begin, void* end, float* ms) {
+  hipError_t e = hipEventElapsedTime(ms, (hipEvent_t)begin, (hipEvent_t)end);
+  if (e != hipSuccess) {
+    cradle_set_error("event_elapsed_ms: %s", hipGetErrorString(e));
+    return CRADLE_ERR_HIP;
+  }
+  return CRADLE_OK;
+}
+
 }  // extern "C"

@@ -72,6 +72,10 @@ struct cradle_step_desc {
   // scratch
   void* workspace;
   int64_t workspace_bytes;
+  // optional profiling: hipEvent_t recorded on the stream right before / after the NB-likelihood
+  // kernels (K1); NULL = off
+  void* ev_k1_begin;
+  void* ev_k1_end;
 };
 
 }  // extern "C"
@@ -398,12 +402,14 @@ int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
   trunk_fwd(c, d.dec, PN, Hd, w.yd, w.rd);
   head_fwd(c, d.dec, PN, Hd, G, w.yd[d.dec.n_layers - 1], w.logits);
   if (c.rc) return c.rc;
+  if (d.ev_k1_begin) (void)hipEventRecord((hipEvent_t)d.ev_k1_begin, s);
   if (!d.compute_grads) {
     STEP(cradle_nb_logprob_fwd(w.logits, G, d.X, G, d.library_size, w.gene_consts, w.recon, P, N, G, s));
   } else {
     STEP(cradle_nb_logprob_fwd_bwd(w.logits, G, w.logits, G, d.X, G, d.library_size, w.gene_consts, w.cp.grow, w.recon,
                                    d.d_log_concentration, 0, w.nbws, w.nbws_floats, P, N, G, s));
   }
+  if (d.ev_k1_end) (void)hipEventRecord((hipEvent_t)d.ev_k1_end, s);
   STEP(finalize_loss(w.recon, w.cp.wrec, w.ltz, w.klrow, w.Smask, w.SE, w.Sq, w.cp.cw, w.cp.cwq, d.beta, P, N, T, Q,
                      d.out, s));
   if (!d.compute_grads) return CRADLE_OK;

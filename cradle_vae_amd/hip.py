@@ -23,6 +23,9 @@ PROTOTYPES = {
     "cradle_last_error": (ctypes.c_char_p, []),
     "cradle_abi_version": (i32, []),
     "cradle_device_count": (i32, []),
+    "cradle_event_create": (i32, [ctypes.POINTER(ctypes.c_void_p)]),
+    "cradle_event_destroy": (i32, [ctypes.c_void_p]),
+    "cradle_event_elapsed_ms": (i32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "cradle_nb_gene_consts": (i32, [c_float_p, c_float_p, i32, c_stream]),
     "cradle_nb_logprob_fwd": (i32, [c_float_p, i64, c_float_p, i64, c_float_p, c_float_p, c_float_p, i32, i32, i32, c_stream]),
     "cradle_nb_logprob_fwd_bwd": (
@@ -74,7 +77,7 @@ class StepDesc(ctypes.Structure):
                                           "u_mask", "eps_E", "eps_qc_E", "eps_z")]
         + [("beta", ctypes.c_float), ("alpha", ctypes.c_float), ("compute_grads", i32)]
         + [("out", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
-           ("workspace_bytes", i64)]
+           ("workspace_bytes", i64), ("ev_k1_begin", ctypes.c_void_p), ("ev_k1_end", ctypes.c_void_p)]
     )
 
 
@@ -144,3 +147,26 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+class EventPair:
+    """Two hipEvent_t handles created through the library (no torch involvement)."""
+
+    def __init__(self):
+        lib = load()
+        self.begin, self.end = ctypes.c_void_p(), ctypes.c_void_p()
+        check(lib.cradle_event_create(ctypes.byref(self.begin)), "event_create")
+        check(lib.cradle_event_create(ctypes.byref(self.end)), "event_create")
+
+    def elapsed_ms(self) -> float:
+        ms = ctypes.c_float()
+        check(load().cradle_event_elapsed_ms(self.begin, self.end, ctypes.byref(ms)), "event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib = load()
+            lib.cradle_event_destroy(self.begin)
+            lib.cradle_event_destroy(self.end)
+        except Exception:
+            pass

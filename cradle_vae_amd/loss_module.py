@@ -82,6 +82,8 @@ class PerturbationPlatedELBOLossModule(torch.nn.Module):
             if self.step == "fused":
                 raise
             return False
+        if not next(self.parameters()).is_cuda and self.step == "auto":
+            return False  # CPU tensors: the module-level path raises inside the first kernel wrapper
         ok = step_mod.supports(self)
         if self.step == "fused" and not ok:
             raise NotImplementedError("this configuration is not supported by the fused HIP step")

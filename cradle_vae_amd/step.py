@@ -143,6 +143,7 @@ class FusedElboStep:
         self._noise = None
         self._calls = 0
         self._shape_key = None
+        self.k1_events = None  # list collecting hip.EventPair around K1 when profiling (bench.py)
 
     # ------------------------------------------------------------------ descriptor
     def _fill_static(self, P, N):
@@ -222,6 +223,12 @@ class FusedElboStep:
         d.beta = float(self.lm.beta)
         d.alpha = -1.0 if self.lm.alpha is None else float(self.lm.alpha)
         d.compute_grads = int(compute_grads)
+        if self.k1_events is not None:
+            ev = hip.EventPair()
+            self.k1_events.append(ev)
+            d.ev_k1_begin, d.ev_k1_end = ev.begin, ev.end
+        else:
+            d.ev_k1_begin, d.ev_k1_end = None, None
         hip.check(self.lib.cradle_elbo_step(ctypes.byref(d), hip.stream()), "cradle_elbo_step")
         self._calls += 1
         if self._calls == 1 or self._calls % 256 == 0:

@@ -28,6 +28,19 @@ class TrainStep:
         self.gen_local = torch.Generator(device=self.device).manual_seed(seed + 7919 * (rank + 1))
         self.impl = "modular"
         self.decoder_variants = 2
+        self.lr, self.weight_decay = lr, weight_decay
+        self.step_count = 0
+        self.fused = None
+        if loss_module._use_fused(None):
+            from . import hip
+
+            self.fused = loss_module._fused_step()
+            self.impl = "fused"
+            self.decoder_variants = 1
+            a = self.fused.arena
+            self.exp_avg = torch.zeros_like(a.flat)
+            self.exp_avg_sq = torch.zeros_like(a.flat)
+            self.norm_ws = torch.zeros(hip.load().cradle_adam_workspace_floats(), device=self.device)
 
     def draw_noise(self, P, N):
         g = self.lm.guide
@@ -58,7 +71,34 @@ class TrainStep:
             p.grad.copy_(flat[off:off + n].view_as(p))
             off += n
 
+    def _fused_call(self, batch, n_particles):
+        from . import hip, ops
+
+        f = self.fused
+        with ops._timed("elbo_step"):
+            out = f.run(
+                X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"],
+                qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
+                n_particles=n_particles, gen_plated=self.gen_plated, gen_local=self.gen_local)
+        a = f.arena
+        if self.world_size > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(a.grad)  # one RCCL call on the flat gradient arena; averaged inside Adam
+        self.step_count += 1
+        hip.check(
+            hip.load().cradle_adam_step(
+                a.flat.data_ptr(), a.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), a.numel,
+                self.lr, 0.9, 0.999, 1e-8, self.weight_decay, self.step_count,
+                float(self.clip) if self.clip is not None else -1.0, 1.0 / self.world_size, self.norm_ws.data_ptr(),
+                hip.stream()),
+            "cradle_adam_step")
+        self.last_out = out
+        return out[0]
+
     def __call__(self, batch: Dict[str, torch.Tensor], n_particles: int) -> torch.Tensor:
+        if self.fused is not None:
+            return self._fused_call(batch, n_particles)
         noise, cf_noise = self.draw_noise(n_particles, batch["X"].shape[0])
         self.optimizer.zero_grad(set_to_none=False)
         loss, metrics = self.lm.loss(

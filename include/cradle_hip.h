@@ -38,6 +38,10 @@ typedef struct ihipStream_t* cradle_stream_t; /* == hipStream_t */
 const char* cradle_last_error(void);
 int cradle_abi_version(void);
 int cradle_device_count(void);
+/* hipEvent helpers for hosts without their own HIP binding (bench.py) */
+int cradle_event_create(void** ev);
+int cradle_event_destroy(void* ev);
+int cradle_event_elapsed_ms(void* begin, void* end, float* ms);
 
 /* ---- K1: Gamma-Poisson (negative binomial) log-likelihood over genes ----------------
  * Replaces, for one decoder variant (good or bad):
@@ -157,6 +161,8 @@ typedef struct cradle_step_desc {
   int* flags;             /* (1) */
   void* workspace;
   int64_t workspace_bytes;
+  void* ev_k1_begin;      /* optional hipEvent_t recorded before / after the K1 launches; NULL = off */
+  void* ev_k1_end;
 } cradle_step_desc;
 
 int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only the sizes are read */
