@@ -74,26 +74,25 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const int* __restrict
   if (threadIdx.x == 0) tstart[T] = carry;
 }
 
+// One wave per treatment scans the ELL entries in (cell, slot) order, 64 at a time; the ballot
+// prefix keeps the order, so every treatment's cell list is ascending (deterministic sums).
 __global__ __launch_bounds__(256) void csc_fill_kernel(const int* __restrict__ ell_idx, const float* __restrict__ ell_val,
                                                        int entries, int kmax, int T, const int* __restrict__ tstart,
                                                        int* __restrict__ csc_cell, float* __restrict__ csc_val) {
-  __shared__ int sidx[4096];
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  int pos = t < T ? tstart[t] : 0;
-  for (int c = 0; c < entries; c += 4096) {
-    const int m = min(4096, entries - c);
-    for (int i = threadIdx.x; i < m; i += 256) sidx[i] = ell_idx[c + i];
-    __syncthreads();
-    if (t < T) {
-      for (int i = 0; i < m; ++i) {
-        if (sidx[i] == t) {
-          csc_cell[pos] = (c + i) / kmax;
-          csc_val[pos] = ell_val[c + i];
-          ++pos;
-        }
-      }
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= T) return;
+  int pos = tstart[t];
+  const int end = tstart[t + 1];
+  for (int c = 0; c < entries && pos < end; c += 64) {
+    const int e = c + lane;
+    const bool hit = e < entries && ell_idx[e] == t;
+    const unsigned long long b = __ballot(hit);
+    if (hit) {
+      const int q = pos + __popcll(b & ((1ull << lane) - 1ull));
+      csc_cell[q] = e / kmax;
+      csc_val[q] = ell_val[e];
     }
-    __syncthreads();
+    pos += __popcll(b);
   }
 }
 
@@ -107,7 +106,7 @@ int build_dosage_plan(const float* D, int N, int T, const DosagePlan& plan, hipS
   hipLaunchKernelGGL(dosage_rows_kernel, dim3(N), dim3(64), 0, stream, D, N, T, plan.kmax, plan.ell_idx, plan.ell_val,
                      plan.tcount, plan.flags);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, plan.tcount, T, plan.tstart);
-  hipLaunchKernelGGL(csc_fill_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, plan.ell_idx, plan.ell_val,
+  hipLaunchKernelGGL(csc_fill_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, plan.ell_idx, plan.ell_val,
                      N * plan.kmax, plan.kmax, T, plan.tstart, plan.csc_cell, plan.csc_val);
   CRADLE_CHECK_LAUNCH("build_dosage_plan");
   return CRADLE_OK;
@@ -685,14 +684,16 @@ __global__ __launch_bounds__(128) void enc_combine_bwd_kernel(const float* __res
   }
 }
 
-// dvq[pp,q,:] = sum_n s_q[n] dpre[variant rows]
-__global__ __launch_bounds__(128) void enc_combine_bwd_vq_kernel(const float* __restrict__ dpre, const float* __restrict__ qc,
-                                                                 float* __restrict__ dvq, int P, int N, int Q, int H) {
-  const int q = blockIdx.x, pp = blockIdx.y;
+// dvq[pp,q,:] = sum_n s_q[n] dpre[variant rows]; 64 columns x 16 cell slices per block
+__global__ __launch_bounds__(1024) void enc_combine_bwd_vq_kernel(const float* __restrict__ dpre, const float* __restrict__ qc,
+                                                                  float* __restrict__ dvq, int P, int N, int Q, int H) {
+  __shared__ float part[16][64];
+  const int q = blockIdx.y % Q, pp = blockIdx.y / Q;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
   const int64_t PN = (int64_t)P * N;
-  for (int j = threadIdx.x; j < H; j += 128) {
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) {
+  float acc = 0.f;
+  if (j < H) {
+    for (int n = sl; n < N; n += 16) {
       const float s = qc[(int64_t)n * Q + q];
       if (pp < P) {
         const int64_t r = (int64_t)pp * N + n;
@@ -702,14 +703,22 @@ __global__ __launch_bounds__(128) void enc_combine_bwd_vq_kernel(const float* __
         acc += (1.0f - s) * dpre[r * H + j];
       }
     }
-    dvq[((int64_t)pp * Q + q) * H + j] = acc;
+  }
+  part[sl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sl == 0 && j < H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+    dvq[((int64_t)pp * Q + q) * H + j] = t;
   }
 }
 
 int enc_combine_bwd(const float* dpre, const float* qc, float* doffW, float* dxW, float* dvq, int P, int N, int Q, int H,
                     hipStream_t stream) {
   hipLaunchKernelGGL(enc_combine_bwd_kernel, dim3(N), dim3(128), 0, stream, dpre, doffW, dxW, P, N, H);
-  hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3(Q, 2 * P), dim3(128), 0, stream, dpre, qc, dvq, P, N, Q, H);
+  hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3((H + 63) / 64, 2 * P * Q), dim3(1024), 0, stream, dpre, qc, dvq, P,
+                     N, Q, H);
   CRADLE_CHECK_LAUNCH("enc_combine_bwd");
   return CRADLE_OK;
 }
@@ -771,18 +780,26 @@ int sum_over_groups_to_cols(const float* da, int groups, int T, int H, float* dW
 }
 
 // out[p, :] = sum_n w[n] da[p*N + n, :]   (gradient of the per-particle bad-variant shift)
-__global__ __launch_bounds__(128) void weighted_rowgroup_sum_kernel(const float* __restrict__ da, const float* __restrict__ w,
-                                                                    int N, int H, float* __restrict__ out) {
-  const int p = blockIdx.x;
-  for (int j = blockIdx.y * 128 + threadIdx.x; j < H; j += gridDim.y * 128) {
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) acc = fmaf(w[n], da[((int64_t)p * N + n) * H + j], acc);
-    out[(int64_t)p * H + j] = acc;
+__global__ __launch_bounds__(1024) void weighted_rowgroup_sum_kernel(const float* __restrict__ da, const float* __restrict__ w,
+                                                                     int N, int H, float* __restrict__ out) {
+  __shared__ float part[16][64];
+  const int p = blockIdx.y;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (j < H)
+    for (int n = sl; n < N; n += 16) acc = fmaf(w[n], da[((int64_t)p * N + n) * H + j], acc);
+  part[sl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sl == 0 && j < H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+    out[(int64_t)p * H + j] = t;
   }
 }
 
 int weighted_rowgroup_sum(const float* da, const float* w, int P, int N, int H, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(weighted_rowgroup_sum_kernel, dim3(P, (H + 127) / 128), dim3(128), 0, stream, da, w, N, H, out);
+  hipLaunchKernelGGL(weighted_rowgroup_sum_kernel, dim3((H + 63) / 64, P), dim3(1024), 0, stream, da, w, N, H, out);
   CRADLE_CHECK_LAUNCH("weighted_rowgroup_sum_kernel");
   return CRADLE_OK;
 }

@@ -21,12 +21,11 @@ namespace cradle {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
-constexpr int KPAD = 4;  // K-major LDS row stride 20 floats: conflict-free ds_read_b128
+constexpr int KPAD = 4;  // K-major LDS row stride BK+4 floats: conflict-free ds_read_b128
 
-template <bool KMAJOR, int ROWS>
+template <bool KMAJOR, int ROWS, int BK>
 struct TileLoader {
-  // One operand tile of ROWS x BK floats per K step; every thread moves ROWS*BK/256/4 float4.
+  // One operand tile of ROWS x BK floats per K step; every thread moves NV float4.
   static constexpr int NV = ROWS * BK / 4 / 256;
   float4 regs[NV];
 
@@ -104,13 +103,31 @@ struct TileLoader {
   }
 };
 
-__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : kLeakySlope * v; }
+// The fused epilogue of one output element (shared by the GEMM kernel and the split-K reducer).
+__device__ __forceinline__ void epilogue(const GemmParams& p, int row, int col, float v) {
+  if (col == p.N) {  // virtual ones column -> bias gradient
+    p.extra_col[row] = v + (p.beta != 0.f ? p.beta * p.extra_col[row] : 0.f);
+    return;
+  }
+  if (p.bias) v += p.bias[col];
+  if (p.rowbias) {
+    const int rb_row = p.rb_mode == 1 ? row / p.rb_n : row % p.rb_n;
+    const float rb = p.rowbias[(int64_t)rb_row * p.ld_rb + col];
+    v += p.rowscale ? p.rowscale[row % p.rs_n] * rb : rb;
+  }
+  if (p.act) v = v > 0.f ? v : kLeakySlope * v;
+  if (p.act_out) p.act_out[(int64_t)row * p.ld_act + col] = v;
+  if (p.res) v += p.res[(int64_t)row * p.ld_res + col];
+  if (p.beta != 0.f) v += p.beta * p.C[(int64_t)row * p.ldc + col];
+  p.C[(int64_t)row * p.ldc + col] = v;
+  if (p.C2) p.C2[(int64_t)row * p.ldc2 + col] = v * (p.dact_src[(int64_t)row * p.ld_ds + col] > 0.f ? 1.f : kLeakySlope);
+}
 
-template <bool A_KMAJOR, bool B_KMAJOR, int TM, int TN, bool VEC>
+template <bool A_KMAJOR, bool B_KMAJOR, int TM, int TN, int BK, int D, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
-  using LA = TileLoader<A_KMAJOR, BM>;
-  using LB = TileLoader<B_KMAJOR, BN>;
+  using LA = TileLoader<A_KMAJOR, BM, BK>;
+  using LB = TileLoader<B_KMAJOR, BN, BK>;
   __shared__ __attribute__((aligned(16))) float lds[2 * (LA::lds_floats() + LB::lds_floats())];
   constexpr int STAGE = LA::lds_floats() + LB::lds_floats();
   auto As = [&](int buf) { return lds + buf * STAGE; };
@@ -149,44 +166,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  LA la;
-  LB lb;
+  // Register prefetch ring of D K-steps: the global loads of step kt+D are issued as soon as
+  // the registers of step kt have been written to LDS, so D-1 steps of MFMA work cover the
+  // L2/HBM latency even with a single wave per SIMD (small-M/N problems give few tiles).
+  LA la[D];
+  LB lb[D];
   const int ones_row = p.extra_col ? p.N : -1;
-  if (kt_begin < kt_end) {
-    la.template load<VEC>(p.A, p.lda, row0, kt_begin * BK, p.M, p.K, -1);
-    lb.template load<VEC>(p.B, p.ldb, col0, kt_begin * BK, p.N, p.K, B_KMAJOR ? -1 : ones_row);
-    la.store(As(0));
-    lb.store(Bs(0));
+#pragma unroll
+  for (int st = 0; st < D; ++st) {
+    if (kt_begin + st < kt_end) {
+      la[st].template load<VEC>(p.A, p.lda, row0, (kt_begin + st) * BK, p.M, p.K, -1);
+      lb[st].template load<VEC>(p.B, p.ldb, col0, (kt_begin + st) * BK, p.N, p.K, B_KMAJOR ? -1 : ones_row);
+    }
   }
-  __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) {
-      la.template load<VEC>(p.A, p.lda, row0, (kt + 1) * BK, p.M, p.K, -1);
-      lb.template load<VEC>(p.B, p.ldb, col0, (kt + 1) * BK, p.N, p.K, B_KMAJOR ? -1 : ones_row);
-    }
+  int kt = kt_begin;
+  while (kt < kt_end) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 8; ++ks) {
-      float4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = LA::frag(As(cur), (wm * TM + i) * 32 + li, ks, lh);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = LB::frag(Bs(cur), (wn * TN + j) * 32 + li, ks, lh);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+    for (int st = 0; st < D; ++st) {
+      if (kt < kt_end) {
+        const int cur = st & 1;  // D is even: the LDS buffer parity continues across ring turns
+        la[st].store(As(cur));
+        lb[st].store(Bs(cur));
+        if (kt + D < kt_end) {
+          la[st].template load<VEC>(p.A, p.lda, row0, (kt + D) * BK, p.M, p.K, -1);
+          lb[st].template load<VEC>(p.B, p.ldb, col0, (kt + D) * BK, p.N, p.K, B_KMAJOR ? -1 : ones_row);
         }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+          float4 a[TM], b[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[i] = LA::frag(As(cur), (wm * TM + i) * 32 + li, ks, lh);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[j] = LB::frag(Bs(cur), (wn * TN + j) * 32 + li, ks, lh);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+            }
+        }
+        ++kt;
+      }
     }
-    if (kt + 1 < kt_end) {
-      la.store(As(cur ^ 1));
-      lb.store(Bs(cur ^ 1));
-    }
-    __syncthreads();
   }
 
   // ---- epilogue.  acc element e of lane: row = (e&3) + 8*(e>>2) + 4*lh, col = li
@@ -196,108 +221,96 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     for (int j = 0; j < TN; ++j) {
       const int col = col0 + (wn * TN + j) * 32 + li;
       if (col >= Np) continue;
-      const float bias = (p.splitk <= 1 && p.bias && col < p.N) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = row0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (row >= p.M) continue;
-        float v = acc[i][j][e];
-        if (p.splitk > 1) {
-          p.partial[((int64_t)blockIdx.z * p.M + row) * Np + col] = v;
-          continue;
-        }
-        if (col == p.N) {  // virtual ones column -> bias gradient
-          p.extra_col[row] = v + (p.beta != 0.f ? p.beta * p.extra_col[row] : 0.f);
-          continue;
-        }
-        v += bias;
-        if (p.rowbias) {
-          const int rb_row = p.rb_mode == 1 ? row / p.rb_n : row % p.rb_n;
-          const float rb = p.rowbias[(int64_t)rb_row * p.ld_rb + col];
-          v += p.rowscale ? p.rowscale[row % p.rs_n] * rb : rb;
-        }
-        if (p.act) v = leaky(v);
-        if (p.act_out) p.act_out[(int64_t)row * p.ld_act + col] = v;
-        if (p.res) v += p.res[(int64_t)row * p.ld_res + col];
-        if (p.beta != 0.f) v += p.beta * p.C[(int64_t)row * p.ldc + col];
-        p.C[(int64_t)row * p.ldc + col] = v;
-        if (p.C2) p.C2[(int64_t)row * p.ldc2 + col] = v * (p.dact_src[(int64_t)row * p.ld_ds + col] > 0.f ? 1.f : kLeakySlope);
+        if (p.splitk > 1) p.partial[((int64_t)blockIdx.z * p.M + row) * Np + col] = acc[i][j][e];
+        else epilogue(p, row, col, acc[i][j][e]);
       }
     }
 }
 
-// Sums the split-K partial tiles and applies beta / the ones-column output.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splitk, int M, int N,
-                                                            int Np, float* __restrict__ C, int64_t ldc, float beta,
-                                                            float* __restrict__ extra_col) {
+// Sums the split-K partial tiles (fixed order: deterministic) and applies the epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+  const int Np = p.N + (p.extra_col ? 1 : 0);
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)M * Np) return;
+  if (idx >= (int64_t)p.M * Np) return;
   const int row = idx / Np, col = idx % Np;
   float v = 0.f;
-  for (int z = 0; z < splitk; ++z) v += partial[((int64_t)z * M + row) * Np + col];
-  if (col == N) {
-    extra_col[row] = v + (beta != 0.f ? beta * extra_col[row] : 0.f);
-  } else {
-    float* c = C + (int64_t)row * ldc + col;
-    *c = v + (beta != 0.f ? beta * *c : 0.f);
-  }
+  for (int z = 0; z < p.splitk; ++z) v += p.partial[((int64_t)z * p.M + row) * Np + col];
+  epilogue(p, row, col, v);
 }
 
 template <bool AK, bool BKM>
-static void launch_cfg(const GemmParams& p, int tm, int tn, bool vec, dim3 grid, hipStream_t s) {
-#define CRADLE_GEMM_CASE(TM_, TN_)                                                                      \
-  if (tm == TM_ && tn == TN_) {                                                                        \
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, true>), grid, dim3(256), 0, s, p); \
-    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, false>), grid, dim3(256), 0, s, p);    \
-    return;                                                                                            \
+static bool launch_cfg(const GemmParams& p, int tm, int tn, int bk, int depth, bool vec, dim3 grid, hipStream_t s) {
+#define CRADLE_GEMM_CASE(TM_, TN_, BK_, D_)                                                                      \
+  if (tm == TM_ && tn == TN_ && bk == BK_ && depth == D_) {                                                     \
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, BK_, D_, true>), grid, dim3(256), 0, s, p); \
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, BK_, D_, false>), grid, dim3(256), 0, s, p);    \
+    return true;                                                                                                \
   }
-  CRADLE_GEMM_CASE(2, 2)
-  CRADLE_GEMM_CASE(1, 2)
-  CRADLE_GEMM_CASE(1, 1)
+  CRADLE_GEMM_CASE(2, 2, 16, 2)
+  CRADLE_GEMM_CASE(2, 2, 16, 4)
+  CRADLE_GEMM_CASE(1, 2, 16, 4)
+  CRADLE_GEMM_CASE(1, 1, 16, 2)
+  CRADLE_GEMM_CASE(1, 1, 16, 4)
+  CRADLE_GEMM_CASE(1, 1, 16, 6)
+  CRADLE_GEMM_CASE(1, 2, 32, 2)
+  CRADLE_GEMM_CASE(1, 1, 32, 2)
+  CRADLE_GEMM_CASE(1, 1, 32, 4)
 #undef CRADLE_GEMM_CASE
+  return false;
 }
 
 int64_t gemm_workspace_floats(int layout, int M, int N, int K, int extra_col) {
   (void)layout;
-  // worst case split factor 32
-  return (int64_t)32 * M * (N + (extra_col ? 1 : 0));
+  (void)K;
+  return (int64_t)32 * M * (N + (extra_col ? 1 : 0));  // worst case split factor 32
 }
 
-// Host-side dispatch.  workspace is only needed when the problem is split along K.
+// manual override for tuning runs (tools/bench_gemm.py): -1 = automatic
+static int g_tune_tm = -1, g_tune_tn = -1, g_tune_bk = -1, g_tune_splitk = -1, g_tune_depth = -1;
+
+// Host-side dispatch.  `workspace` lets the problem split along K (partials + reducer).
 int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_floats, hipStream_t stream) {
   CRADLE_CHECK_ARG(layout >= 0 && layout <= 2, "gemm: bad layout %d", layout);
   CRADLE_CHECK_ARG(p.A && p.B && p.C && p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad arguments M=%d N=%d K=%d", p.M, p.N, p.K);
   CRADLE_CHECK_ARG(!p.extra_col || layout == 2, "gemm: the ones-column output needs the TN layout");
   const int Np = p.N + (p.extra_col ? 1 : 0);
-  // tile choice: the largest tile that still gives every CU a workgroup
-  int tm = 2, tn = 2;
   auto tiles = [&](int tm_, int tn_) { return (int64_t)((p.M + 64 * tm_ - 1) / (64 * tm_)) * ((Np + 64 * tn_ - 1) / (64 * tn_)); };
-  if (tiles(2, 2) < 256) { tm = 1; tn = 2; }
-  if (tm == 1 && tiles(1, 2) < 256) { tm = 1; tn = 1; }
+  // Heuristics from tools/tune_gemm.py sweeps on MI355X at the ELBO step's shapes: 64x64 tiles
+  // (four waves, one 32x32 MFMA tile each) win everywhere below ~1000 tiles of 128x128 because a
+  // few hundred large tiles leave whole rounds of CUs idle; long-K problems are split along K
+  // until ~2048 workgroups are in flight, never below 16 K-steps (256 values of k) per split.
+  int tm = 1, tn = 1, bk = 16, depth = 4;
+  if (tiles(2, 2) >= 1024) { tm = 2; tn = 2; depth = 2; }
+  if (g_tune_tm > 0) { tm = g_tune_tm; tn = g_tune_tn; bk = g_tune_bk; depth = g_tune_depth; }
   const int64_t ntiles = tiles(tm, tn);
-  const int k_tiles = (p.K + BK - 1) / BK;
+  const int k_tiles = (p.K + bk - 1) / bk;
   int splitk = 1;
-  const bool plain = !p.bias && !p.rowbias && !p.act && !p.act_out && !p.res && !p.C2;
-  if (plain && workspace && ntiles < 192 && k_tiles >= 16) {
-    splitk = (int)min((int64_t)32, (384 + ntiles - 1) / ntiles);
-    splitk = min(splitk, k_tiles / 8);
-    while (splitk > 1 && (int64_t)splitk * p.M * Np > workspace_floats) --splitk;
-    if (splitk < 1) splitk = 1;
+  if (workspace && ntiles < 2048) {
+    splitk = (int)min((int64_t)16, (2048 + ntiles - 1) / ntiles);
+    splitk = max(1, min(splitk, k_tiles / 16));
   }
+  if (g_tune_splitk > 0) splitk = g_tune_splitk;
+  if (!workspace) splitk = 1;
+  while (splitk > 1 && (int64_t)splitk * p.M * Np > workspace_floats) --splitk;
+  p.k_tiles_per_split = (k_tiles + splitk - 1) / splitk;
+  splitk = (k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
   p.splitk = splitk;
   p.partial = workspace;
-  p.k_tiles_per_split = (k_tiles + splitk - 1) / splitk;
-  if (splitk > 1) p.splitk = splitk = (k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
   const bool aligned = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.B % 16 == 0) && p.lda % 4 == 0 && p.ldb % 4 == 0;
   dim3 grid((unsigned)ntiles, 1, (unsigned)splitk);
-  if (layout == 0) launch_cfg<true, true>(p, tm, tn, aligned, grid, stream);
-  else if (layout == 1) launch_cfg<true, false>(p, tm, tn, aligned, grid, stream);
-  else launch_cfg<false, false>(p, tm, tn, aligned, grid, stream);
+  bool ok;
+  if (layout == 0) ok = launch_cfg<true, true>(p, tm, tn, bk, depth, aligned, grid, stream);
+  else if (layout == 1) ok = launch_cfg<true, false>(p, tm, tn, bk, depth, aligned, grid, stream);
+  else ok = launch_cfg<false, false>(p, tm, tn, bk, depth, aligned, grid, stream);
+  CRADLE_CHECK_ARG(ok, "gemm: no kernel for tile %dx%d bk %d depth %d", tm, tn, bk, depth);
   CRADLE_CHECK_LAUNCH("gemm_f32_kernel");
   if (splitk > 1) {
     const int64_t total = (int64_t)p.M * Np;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, workspace,
-                       splitk, p.M, p.N, Np, p.C, p.ldc, p.beta, p.extra_col);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
     CRADLE_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return CRADLE_OK;
@@ -308,6 +321,12 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
 using namespace cradle;
 
 extern "C" {
+
+// Tuning hook (not used by the product path): force tile (tm, tn in {1,2}), K step and split; -1 = auto.
+void cradle_gemm_tune(int tm, int tn, int bk, int depth, int splitk) {
+  cradle::g_tune_tm = tm; cradle::g_tune_tn = tn; cradle::g_tune_bk = bk; cradle::g_tune_depth = depth;
+  cradle::g_tune_splitk = splitk;
+}
 
 // Public descriptor (include/cradle_hip.h: cradle_gemm_desc).  Field order is ABI.
 struct cradle_gemm_desc {

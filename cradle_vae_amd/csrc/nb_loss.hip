@@ -191,20 +191,22 @@ __global__ void nb_gene_consts_kernel(const float* __restrict__ log_c, float* __
   gc[2 * (int64_t)G + g] = (float)ps;
 }
 
-// Deterministic column sum of the (rows, G) partials written by nb_rows_kernel.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int rows, int G,
-                                                      float* __restrict__ out, int accumulate) {
-  // block (64 columns x 4 row-groups); each thread walks rows rg, rg+4, ...
-  __shared__ float sm[4][64];
+// Deterministic column sum of the (rows, G) partials written by nb_rows_kernel:
+// 64 columns x 16 row slices per block.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part, int rows, int G,
+                                                       float* __restrict__ out, int accumulate) {
+  __shared__ float sm[16][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
   float acc = 0.f;
   if (col < G)
-    for (int r = rg; r < rows; r += 4) acc += part[(int64_t)r * G + col];
+    for (int r = rg; r < rows; r += 16) acc += part[(int64_t)r * G + col];
   sm[rg][threadIdx.x & 63] = acc;
   __syncthreads();
   if (rg == 0 && col < G) {
-    const float t = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][threadIdx.x];
     out[col] = accumulate ? out[col] + t : t;
   }
 }
@@ -299,7 +301,7 @@ int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlo
   rc = launch_nb_rows<true>(logits, ld_logits, dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, workspace,
                             P, N, G, PS, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_kernel, dim3((G + 63) / 64), dim3(256), 0, stream, workspace, N * PS, G, dlog_c,
+  hipLaunchKernelGGL(colsum_kernel, dim3((G + 63) / 64), dim3(1024), 0, stream, workspace, N * PS, G, dlog_c,
                      accumulate_dlog_c);
   CRADLE_CHECK_LAUNCH("colsum_kernel");
   return CRADLE_OK;

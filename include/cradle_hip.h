@@ -108,6 +108,9 @@ typedef struct cradle_gemm_desc {
 /* workspace (optional, may be NULL): lets small-output / long-K problems split along K. */
 int cradle_gemm_f32(const cradle_gemm_desc* desc, float* workspace, int64_t workspace_floats, cradle_stream_t stream);
 int64_t cradle_gemm_workspace_floats(int layout, int M, int N, int K, int extra_col);
+/* tuning hook for tools/tune_gemm.py: force the tile (tm, tn in {1,2} x 64), K step (16/32),
+ * prefetch depth and K split; -1 = automatic.  Not used on the product path. */
+void cradle_gemm_tune(int tm, int tn, int bk, int depth, int splitk);
 
 /* ---- The fused ELBO step ---------------------------------------------------------------
  * Forward + backward of PerturbationPlatedELBOLossModule.loss

@@ -1,0 +1,59 @@
+"""Sweep tile / K-step / K-split of the fp32 MFMA GEMM at the ELBO step's shapes (GPU only)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cradle_vae_amd import ops, hip
+
+dev = "cuda:0"
+lib = hip.load()
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+shapes = [
+    (ops.NT, 2560, 5000, 400, "dec out fwd"), (ops.NN, 2560, 400, 5000, "dec out dgrad"),
+    (ops.TN, 5000, 400, 2560, "dec out wgrad"), (ops.NT, 1024, 400, 5000, "xW fwd"),
+    (ops.TN, 400, 5000, 1024, "xW wgrad"), (ops.NT, 2560, 400, 400, "hidden fwd"),
+    (ops.NN, 2560, 400, 400, "hidden dgrad"), (ops.TN, 400, 400, 2560, "hidden wgrad"),
+    (ops.NT, 7680, 400, 400, "enc heads fwd"), (ops.NN, 7680, 400, 400, "enc heads dgrad"),
+    (ops.TN, 400, 400, 7680, "enc heads wgrad"), (ops.NT, 1050, 400, 400, "emb fwd"),
+    (ops.NN, 1050, 400, 400, "emb dgrad"), (ops.TN, 400, 400, 1050, "emb wgrad"),
+    (ops.NT, 2560, 400, 200, "offW fwd"), (ops.NN, 5120, 200, 400, "offW dgrad"), (ops.TN, 400, 200, 2560, "offW wgrad"),
+    (ops.NT, 1, 400, 400, "qc enc"),
+]
+cfgs = [(2, 2, 16, 2), (2, 2, 16, 4), (1, 2, 16, 4), (1, 2, 32, 2), (1, 1, 16, 2), (1, 1, 16, 4), (1, 1, 16, 6), (1, 1, 32, 2), (1, 1, 32, 4)]
+splits = [1, 2, 4, 8, 16]
+for layout, M, N, K, what in shapes:
+    if layout == ops.NT:
+        A, B = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
+    elif layout == ops.NN:
+        A, B = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev)
+    else:
+        A, B = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev)
+    out = torch.empty(M, N, device=dev)
+    ws = torch.empty(min(lib.cradle_gemm_workspace_floats(layout, M, N, K, 0), 1 << 26), device=dev)
+    lib.cradle_gemm_tune(-1, -1, -1, -1, -1)
+    t_auto = timeit(lambda: ops.gemm(layout, A, B, out=out, workspace=ws))
+    res = []
+    for tm, tn, bk, dp in cfgs:
+        for sk in splits:
+            if sk > max(1, (K + bk - 1) // bk // 2):
+                continue
+            lib.cradle_gemm_tune(tm, tn, bk, dp, sk)
+            res.append((timeit(lambda: ops.gemm(layout, A, B, out=out, workspace=ws)), tm, tn, f"{bk}d{dp}", sk))
+    lib.cradle_gemm_tune(-1, -1, -1, -1, -1)
+    res.sort()
+    fl = 2.0 * M * N * K
+    best = " | ".join(f"{t*1e6:6.1f}us t{tm}{tn} bk{bk} s{sk}" for t, tm, tn, bk, sk in res[:4])
+    print(f"{what:16s} L{layout} {M}x{N}x{K}: auto {t_auto*1e6:6.1f}us {fl/t_auto/1e12:5.1f}TF || best {fl/res[0][0]/1e12:5.1f}TF: {best}", flush=True)
