@@ -23,70 +23,76 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KPAD = 4;  // K-major LDS row stride BK+4 floats: conflict-free ds_read_b128
 
-template <bool KMAJOR, int ROWS, int BK>
+template <bool KMAJOR, int ROWS, int BK, int NT>
 struct TileLoader {
   // One operand tile of ROWS x BK floats per K step; every thread moves NV float4.
-  static constexpr int NV = ROWS * BK / 4 / 256;
+  static constexpr int NV = ROWS * BK / 4 / NT;
+  static_assert(NV >= 1, "tile too small for the thread count");
   float4 regs[NV];
 
   // row0: first tile row (M or N index), k0: first k.  rows/kdim: logical extents.
   // ones_row: (MN-major only) logical row index whose value is 1 for every k < kdim, or -1.
-  template <bool VEC>
-  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int k0, int rows,
-                                       int kdim, int ones_row) {
+  // FAST: pointers/leading dimensions 16-byte aligned and the contiguous extent a multiple of 4,
+  // so every float4 is either fully inside or fully outside.  The load is a raw buffer load
+  // whose byte offset is pushed past the descriptor's range when the float4 is outside: the
+  // hardware range check returns zeros, nothing depends on the loaded value until the LDS
+  // store, and no branch surrounds a load -- otherwise hipcc waits vmcnt(0) at the joins (or
+  // at a data select) and the prefetch ring below degenerates to one latency per K step.
+  template <bool FAST>
+  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, uint32_t bytes, int row0, int k0,
+                                       int rows, int kdim) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, bytes, 0x00020000);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const int idx = v * 256 + threadIdx.x;
+      const int idx = v * NT + threadIdx.x;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (KMAJOR) {
-        const int r = row0 + idx / (BK / 4);
-        const int k = k0 + (idx % (BK / 4)) * 4;
+      const int r = KMAJOR ? row0 + idx / (BK / 4) : row0 + (idx % (ROWS / 4)) * 4;
+      const int k = KMAJOR ? k0 + (idx % (BK / 4)) * 4 : k0 + idx / (ROWS / 4);
+      if (FAST) {
+        const uint32_t off = KMAJOR ? (uint32_t)(((int64_t)r * ld + k) * 4) : (uint32_t)(((int64_t)k * ld + r) * 4);
+        const bool in = r < rows && k < kdim;
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, in ? off : 0x80000000u, 0, 0);
+        val = __builtin_bit_cast(float4, t);
+      } else if (KMAJOR) {
         if (r < rows) {
           const float* p = P + (int64_t)r * ld + k;
-          if (VEC && k + 3 < kdim) {
-            val = *reinterpret_cast<const float4*>(p);
-          } else {
-            if (k < kdim) val.x = p[0];
-            if (k + 1 < kdim) val.y = p[1];
-            if (k + 2 < kdim) val.z = p[2];
-            if (k + 3 < kdim) val.w = p[3];
-          }
+          if (k < kdim) val.x = p[0];
+          if (k + 1 < kdim) val.y = p[1];
+          if (k + 2 < kdim) val.z = p[2];
+          if (k + 3 < kdim) val.w = p[3];
         }
-      } else {
-        const int k = k0 + idx / (ROWS / 4);
-        const int r = row0 + (idx % (ROWS / 4)) * 4;
-        if (k < kdim) {
-          const float* p = P + (int64_t)k * ld + r;
-          if (VEC && r + 3 < rows) {
-            val = *reinterpret_cast<const float4*>(p);
-          } else {
-            if (r < rows) val.x = p[0];
-            if (r + 1 < rows) val.y = p[1];
-            if (r + 2 < rows) val.z = p[2];
-            if (r + 3 < rows) val.w = p[3];
-          }
-          if (ones_row >= 0) {  // virtual column (index == rows): never read from memory
-            if (r == ones_row) val.x = 1.f;
-            if (r + 1 == ones_row) val.y = 1.f;
-            if (r + 2 == ones_row) val.z = 1.f;
-            if (r + 3 == ones_row) val.w = 1.f;
-          }
-        }
+      } else if (k < kdim) {
+        const float* p = P + (int64_t)k * ld + r;
+        if (r < rows) val.x = p[0];
+        if (r + 1 < rows) val.y = p[1];
+        if (r + 2 < rows) val.z = p[2];
+        if (r + 3 < rows) val.w = p[3];
       }
       regs[v] = val;
     }
   }
 
-  __device__ __forceinline__ void store(float* lds) const {
+  // ones_row >= 0 (MN-major B of a wgrad only): logical row whose value is 1 for every k < kdim --
+  // the virtual all-ones column that turns the bias gradient into one more output column.
+  __device__ __forceinline__ void store(float* lds, int row0, int k0, int kdim, int ones_row) const {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const int idx = v * 256 + threadIdx.x;
+      const int idx = v * NT + threadIdx.x;
       if (KMAJOR) {
         const int r = idx / (BK / 4), k4 = idx % (BK / 4);
         *reinterpret_cast<float4*>(lds + r * (BK + KPAD) + k4 * 4) = regs[v];
       } else {
         const int k = idx / (ROWS / 4), r4 = idx % (ROWS / 4);
-        *reinterpret_cast<float4*>(lds + k * ROWS + r4 * 4) = regs[v];
+        float4 val = regs[v];
+        if (ones_row >= 0 && k0 + k < kdim) {
+          const int r = row0 + r4 * 4;
+          val.x = (r == ones_row) ? 1.f : val.x;
+          val.y = (r + 1 == ones_row) ? 1.f : val.y;
+          val.z = (r + 2 == ones_row) ? 1.f : val.z;
+          val.w = (r + 3 == ones_row) ? 1.f : val.w;
+        }
+        *reinterpret_cast<float4*>(lds + k * ROWS + r4 * 4) = val;
       }
     }
   }
@@ -123,11 +129,15 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int row, int col, 
   if (p.C2) p.C2[(int64_t)row * p.ldc2 + col] = v * (p.dact_src[(int64_t)row * p.ld_ds + col] > 0.f ? 1.f : kLeakySlope);
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, int TM, int TN, int BK, int D, bool VEC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
-  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
-  using LA = TileLoader<A_KMAJOR, BM, BK>;
-  using LB = TileLoader<B_KMAJOR, BN, BK>;
+// WK = 2: eight waves per workgroup; waves 4-7 take the second half of every K step of the same
+// 2x2 arrangement of 32x32 tiles, so each SIMD holds two waves whose LDS round trips
+// (write -> barrier -> fragment read) hide behind the other's MFMA chain; their partial
+// accumulators are summed through LDS before the epilogue.
+template <bool A_KMAJOR, bool B_KMAJOR, int TM, int TN, int BK, int D, int WK, bool VEC>
+__global__ __launch_bounds__(256 * WK) void gemm_f32_kernel(const GemmParams p) {
+  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, NT = 256 * WK;
+  using LA = TileLoader<A_KMAJOR, BM, BK, NT>;
+  using LB = TileLoader<B_KMAJOR, BN, BK, NT>;
   __shared__ __attribute__((aligned(16))) float lds[2 * (LA::lds_floats() + LB::lds_floats())];
   constexpr int STAGE = LA::lds_floats() + LB::lds_floats();
   auto As = [&](int buf) { return lds + buf * STAGE; };
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   const int tile_m = wg / tiles_n, tile_n = wg % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, kgroup = threadIdx.x >> 8;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
@@ -168,50 +178,69 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 
   // Register prefetch ring of D K-steps: the global loads of step kt+D are issued as soon as
   // the registers of step kt have been written to LDS, so D-1 steps of MFMA work cover the
-  // L2/HBM latency even with a single wave per SIMD (small-M/N problems give few tiles).
+  // L2/HBM latency even with a single wave per SIMD.  The step count is rounded up to a
+  // multiple of D; steps past the end load zeros (select, no branch), which the MFMAs absorb.
   LA la[D];
   LB lb[D];
   const int ones_row = p.extra_col ? p.N : -1;
+  const int k_limit = min(p.K, kt_end * BK);  // this split's K range ends here
+  const int n_steps = (kt_end - kt_begin + D - 1) / D * D;
+  const int ones_b = B_KMAJOR ? -1 : ones_row;
 #pragma unroll
   for (int st = 0; st < D; ++st) {
-    if (kt_begin + st < kt_end) {
-      la[st].template load<VEC>(p.A, p.lda, row0, (kt_begin + st) * BK, p.M, p.K, -1);
-      lb[st].template load<VEC>(p.B, p.ldb, col0, (kt_begin + st) * BK, p.N, p.K, B_KMAJOR ? -1 : ones_row);
-    }
+    la[st].template load<VEC>(p.A, p.lda, p.a_bytes, row0, (kt_begin + st) * BK, p.M, k_limit);
+    lb[st].template load<VEC>(p.B, p.ldb, p.b_bytes, col0, (kt_begin + st) * BK, p.N, k_limit);
   }
-  int kt = kt_begin;
-  while (kt < kt_end) {
+  for (int kt = kt_begin; kt < kt_begin + n_steps; kt += D) {
 #pragma unroll
     for (int st = 0; st < D; ++st) {
-      if (kt < kt_end) {
-        const int cur = st & 1;  // D is even: the LDS buffer parity continues across ring turns
-        la[st].store(As(cur));
-        lb[st].store(Bs(cur));
-        if (kt + D < kt_end) {
-          la[st].template load<VEC>(p.A, p.lda, row0, (kt + D) * BK, p.M, p.K, -1);
-          lb[st].template load<VEC>(p.B, p.ldb, col0, (kt + D) * BK, p.N, p.K, B_KMAJOR ? -1 : ones_row);
-        }
-        __syncthreads();
+      const int cur = st & 1;  // D is even: the LDS buffer parity continues across ring turns
+      la[st].store(As(cur), row0, (kt + st) * BK, k_limit, -1);
+      lb[st].store(Bs(cur), col0, (kt + st) * BK, k_limit, ones_b);
+      la[st].template load<VEC>(p.A, p.lda, p.a_bytes, row0, (kt + st + D) * BK, p.M, k_limit);
+      lb[st].template load<VEC>(p.B, p.ldb, p.b_bytes, col0, (kt + st + D) * BK, p.N, k_limit);
+      __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-          float4 a[TM], b[TN];
+      for (int kq = 0; kq < BK / 8 / WK; ++kq) {
+        const int ks = kgroup * (BK / 8 / WK) + kq;
+        float4 a[TM], b[TN];
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a[i] = LA::frag(As(cur), (wm * TM + i) * 32 + li, ks, lh);
+        for (int i = 0; i < TM; ++i) a[i] = LA::frag(As(cur), (wm * TM + i) * 32 + li, ks, lh);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) b[j] = LB::frag(Bs(cur), (wn * TN + j) * 32 + li, ks, lh);
+        for (int j = 0; j < TN; ++j) b[j] = LB::frag(Bs(cur), (wn * TN + j) * 32 + li, ks, lh);
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-            }
-        }
-        ++kt;
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+          }
       }
     }
+  }
+
+  if (WK > 1) {  // sum the K halves: waves 4-7 park their accumulators in LDS, waves 0-3 add them
+    static_assert(WK == 1 || 2 * STAGE >= 4 * TM * TN * 16 * 64, "LDS too small for the K-half reduction");
+    __syncthreads();
+    float* red = lds + (size_t)wave * (TM * TN * 16 * 64);
+    if (kgroup == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) red[((i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (kgroup == 1) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += red[((i * TN + j) * 16 + e) * 64 + lane];
   }
 
   // ---- epilogue.  acc element e of lane: row = (e&3) + 8*(e>>2) + 4*lh, col = li
@@ -243,22 +272,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 }
 
 template <bool AK, bool BKM>
-static bool launch_cfg(const GemmParams& p, int tm, int tn, int bk, int depth, bool vec, dim3 grid, hipStream_t s) {
-#define CRADLE_GEMM_CASE(TM_, TN_, BK_, D_)                                                                      \
-  if (tm == TM_ && tn == TN_ && bk == BK_ && depth == D_) {                                                     \
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, BK_, D_, true>), grid, dim3(256), 0, s, p); \
-    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, BK_, D_, false>), grid, dim3(256), 0, s, p);    \
-    return true;                                                                                                \
+static bool launch_cfg(const GemmParams& p, int tm, int tn, int bk, int depth, int wk, bool vec, dim3 grid,
+                       hipStream_t s) {
+#define CRADLE_GEMM_CASE(TM_, TN_, BK_, D_, WK_)                                                              \
+  if (tm == TM_ && tn == TN_ && bk == BK_ && depth == D_ && wk == WK_) {                                       \
+    if (vec)                                                                                                   \
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, BK_, D_, WK_, true>), grid, dim3(256 * WK_), 0, s, p);  \
+    else                                                                                                       \
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, BK_, D_, WK_, false>), grid, dim3(256 * WK_), 0, s, p); \
+    return true;                                                                                               \
   }
-  CRADLE_GEMM_CASE(2, 2, 16, 2)
-  CRADLE_GEMM_CASE(2, 2, 16, 4)
-  CRADLE_GEMM_CASE(1, 2, 16, 4)
-  CRADLE_GEMM_CASE(1, 1, 16, 2)
-  CRADLE_GEMM_CASE(1, 1, 16, 4)
-  CRADLE_GEMM_CASE(1, 1, 16, 6)
-  CRADLE_GEMM_CASE(1, 2, 32, 2)
-  CRADLE_GEMM_CASE(1, 1, 32, 2)
-  CRADLE_GEMM_CASE(1, 1, 32, 4)
+  CRADLE_GEMM_CASE(2, 2, 16, 2, 1)
+  CRADLE_GEMM_CASE(1, 1, 16, 2, 1)
+  CRADLE_GEMM_CASE(1, 1, 16, 4, 1)
+  CRADLE_GEMM_CASE(1, 1, 32, 2, 1)
+  CRADLE_GEMM_CASE(1, 1, 32, 2, 2)
+  CRADLE_GEMM_CASE(1, 1, 32, 4, 2)
+  CRADLE_GEMM_CASE(1, 2, 32, 2, 2)
+  CRADLE_GEMM_CASE(2, 2, 32, 2, 2)
 #undef CRADLE_GEMM_CASE
   return false;
 }
@@ -270,7 +301,7 @@ int64_t gemm_workspace_floats(int layout, int M, int N, int K, int extra_col) {
 }
 
 // manual override for tuning runs (tools/bench_gemm.py): -1 = automatic
-static int g_tune_tm = -1, g_tune_tn = -1, g_tune_bk = -1, g_tune_splitk = -1, g_tune_depth = -1;
+static int g_tune_tm = -1, g_tune_tn = -1, g_tune_bk = -1, g_tune_splitk = -1, g_tune_depth = -1, g_tune_wk = -1;
 
 // Host-side dispatch.  `workspace` lets the problem split along K (partials + reducer).
 int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_floats, hipStream_t stream) {
@@ -283,9 +314,9 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
   // (four waves, one 32x32 MFMA tile each) win everywhere below ~1000 tiles of 128x128 because a
   // few hundred large tiles leave whole rounds of CUs idle; long-K problems are split along K
   // until ~2048 workgroups are in flight, never below 16 K-steps (256 values of k) per split.
-  int tm = 1, tn = 1, bk = 16, depth = 4;
+  int tm = 1, tn = 1, bk = 16, depth = 4, wk = 1;
   if (tiles(2, 2) >= 1024) { tm = 2; tn = 2; depth = 2; }
-  if (g_tune_tm > 0) { tm = g_tune_tm; tn = g_tune_tn; bk = g_tune_bk; depth = g_tune_depth; }
+  if (g_tune_tm > 0) { tm = g_tune_tm; tn = g_tune_tn; bk = g_tune_bk; depth = g_tune_depth; wk = g_tune_wk; }
   const int64_t ntiles = tiles(tm, tn);
   const int k_tiles = (p.K + bk - 1) / bk;
   int splitk = 1;
@@ -300,13 +331,23 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
   splitk = (k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
   p.splitk = splitk;
   p.partial = workspace;
-  const bool aligned = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.B % 16 == 0) && p.lda % 4 == 0 && p.ldb % 4 == 0;
+  // branch-free loader: everything 16-byte aligned and the contiguous extents multiples of 4
+  const int64_t a_rows = layout == 2 ? p.K : p.M, a_cols = layout == 2 ? p.M : p.K;
+  const int64_t b_rows = layout == 0 ? p.N : p.K, b_cols = layout == 0 ? p.K : p.N;
+  const int64_t a_bytes = ((a_rows - 1) * p.lda + a_cols) * 4, b_bytes = ((b_rows - 1) * p.ldb + b_cols) * 4;
+  p.a_bytes = (uint32_t)a_bytes;
+  p.b_bytes = (uint32_t)b_bytes;
+  bool aligned = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.B % 16 == 0) && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
+                 p.K >= 4 && a_bytes < (1ll << 31) && b_bytes < (1ll << 31);
+  if (layout == 0) aligned = aligned && p.K % 4 == 0;
+  else if (layout == 1) aligned = aligned && p.K % 4 == 0 && p.N % 4 == 0 && p.N >= 4;
+  else aligned = aligned && p.M % 4 == 0 && p.N % 4 == 0 && p.M >= 4 && p.N >= 4;
   dim3 grid((unsigned)ntiles, 1, (unsigned)splitk);
   bool ok;
-  if (layout == 0) ok = launch_cfg<true, true>(p, tm, tn, bk, depth, aligned, grid, stream);
-  else if (layout == 1) ok = launch_cfg<true, false>(p, tm, tn, bk, depth, aligned, grid, stream);
-  else ok = launch_cfg<false, false>(p, tm, tn, bk, depth, aligned, grid, stream);
-  CRADLE_CHECK_ARG(ok, "gemm: no kernel for tile %dx%d bk %d depth %d", tm, tn, bk, depth);
+  if (layout == 0) ok = launch_cfg<true, true>(p, tm, tn, bk, depth, wk, aligned, grid, stream);
+  else if (layout == 1) ok = launch_cfg<true, false>(p, tm, tn, bk, depth, wk, aligned, grid, stream);
+  else ok = launch_cfg<false, false>(p, tm, tn, bk, depth, wk, aligned, grid, stream);
+  CRADLE_CHECK_ARG(ok, "gemm: no kernel for tile %dx%d bk %d depth %d wk %d", tm, tn, bk, depth, wk);
   CRADLE_CHECK_LAUNCH("gemm_f32_kernel");
   if (splitk > 1) {
     const int64_t total = (int64_t)p.M * Np;
@@ -323,9 +364,9 @@ using namespace cradle;
 extern "C" {
 
 // Tuning hook (not used by the product path): force tile (tm, tn in {1,2}), K step and split; -1 = auto.
-void cradle_gemm_tune(int tm, int tn, int bk, int depth, int splitk) {
+void cradle_gemm_tune(int tm, int tn, int bk, int depth, int wk, int splitk) {
   cradle::g_tune_tm = tm; cradle::g_tune_tn = tn; cradle::g_tune_bk = bk; cradle::g_tune_depth = depth;
-  cradle::g_tune_splitk = splitk;
+  cradle::g_tune_wk = wk; cradle::g_tune_splitk = splitk;
 }
 
 // Public descriptor (include/cradle_hip.h: cradle_gemm_desc).  Field order is ABI.
@@ -360,6 +401,17 @@ int cradle_gemm_f32(const cradle_gemm_desc* d, float* workspace, int64_t workspa
   CRADLE_CHECK_ARG(!p.rowbias || ((p.rb_mode == 1 || p.rb_mode == 2) && p.rb_n > 0), "gemm: bad rowbias mode");
   CRADLE_CHECK_ARG(!p.rowscale || (p.rowbias && p.rs_n > 0), "gemm: rowscale needs rowbias");
   return gemm_f32(d->layout, p, workspace, workspace_floats, stream);
+}
+
+// Tuning / benchmarking aid: the same GEMM launched `repeat` times back to back from C, so that a
+// Python caller measures kernel time rather than its own per-call overhead.
+int cradle_gemm_f32_repeat(const cradle_gemm_desc* d, float* workspace, int64_t workspace_floats, int repeat,
+                           hipStream_t stream) {
+  for (int i = 0; i < repeat; ++i) {
+    int rc = cradle_gemm_f32(d, workspace, workspace_floats, stream);
+    if (rc) return rc;
+  }
+  return CRADLE_OK;
 }
 
 int64_t cradle_gemm_workspace_floats(int layout, int M, int N, int K, int extra_col) {

@@ -28,6 +28,7 @@ struct GemmParams {
   float* C2;
   int64_t ldc2;
   float* extra_col;       // TN only: B gets a virtual all-ones column N; its result goes here [M]
+  uint32_t a_bytes, b_bytes;  // filled by gemm_f32: operand extents for the buffer descriptors
   int splitk;             // filled by gemm_f32
   float* partial;
   int k_tiles_per_split;

@@ -108,11 +108,13 @@ struct Work {
   float *yz[CRADLE_MAX_LAYERS], *rz[CRADLE_MAX_LAYERS], *headsz, *sdz, *ltz, *klrow;
   float *wq, *yd[CRADLE_MAX_LAYERS], *rd[CRADLE_MAX_LAYERS], *logits, *recon, *nbws;
   // backward
-  float *Gd[2], *dad[2], *dzoff, *dwq, *dq_dec;
-  float *dheadsz, *Gz[2], *daz[2], *doffW, *dxW, *dvq, *doffenc, *dq_enc;
-  float *dME, *dmaskME, *dheadsE, *GE[2], *daE[2], *dmask_enc;
-  float *dheadsq, *Gq[2], *daq[2];
-  float* splitk;
+  // backward: G ping-pongs on the main stream; the pre-activation gradients da[k] are kept per
+  // layer because the weight-gradient GEMMs read them from a side stream
+  float *Gd[2], *dad[CRADLE_MAX_LAYERS], *dzoff, *dwq, *dq_dec;
+  float *dheadsz, *Gz[2], *daz[CRADLE_MAX_LAYERS], *doffW, *dxW, *dvq, *doffenc, *dq_enc;
+  float *dME, *dmaskME, *dheadsE, *GE[2], *daE[CRADLE_MAX_LAYERS], *dmask_enc;
+  float *dheadsq, *Gq[2], *daq[CRADLE_MAX_LAYERS];
+  float* splitk[3];  // one split-K scratch per stream
   int64_t nbws_floats;
 };
 
@@ -187,14 +189,14 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   w.nbws = a.take<float>(w.nbws_floats);
   for (int i = 0; i < 2; ++i) {
     w.Gd[i] = a.take<float>(PN * Hd);
-    w.dad[i] = a.take<float>(PN * Hd);
     w.Gz[i] = a.take<float>(3 * PN * He);
-    w.daz[i] = a.take<float>(3 * PN * He);
     w.GE[i] = a.take<float>(PT * Hm);
-    w.daE[i] = a.take<float>(PT * Hm);
     w.Gq[i] = a.take<float>((int64_t)Q * Hm);
-    w.daq[i] = a.take<float>((int64_t)Q * Hm);
   }
+  for (int k = 0; k < d.dec.n_layers; ++k) w.dad[k] = a.take<float>(PN * Hd);
+  for (int k = 0; k < d.enc.n_layers; ++k) w.daz[k] = a.take<float>(3 * PN * He);
+  for (int k = 0; k < d.emb.n_layers; ++k) w.daE[k] = a.take<float>(PT * Hm);
+  for (int k = 0; k < d.qce.n_layers; ++k) w.daq[k] = a.take<float>((int64_t)Q * Hm);
   w.dzoff = a.take<float>(PN * 2 * L);
   w.dwq = a.take<float>((int64_t)P * Hd);
   w.dq_dec = a.take<float>((int64_t)P * L);
@@ -209,18 +211,71 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   w.dheadsE = a.take<float>(PT * 2 * L);
   w.dmask_enc = a.take<float>(PT * L);
   w.dheadsq = a.take<float>((int64_t)Q * 2 * L);
-  w.splitk = a.take<float>(kSplitKFloats);
+  for (int i = 0; i < 3; ++i) w.splitk[i] = a.take<float>(kSplitKFloats);
   return (a.off + 255) & ~int64_t(255);
 }
 
+// Side streams and fork/join events of the step, created once per device.  The step is a DAG
+// (the x Wx^T product, the qc encoder, and every weight-gradient GEMM are off the critical
+// path); most of its kernels fill only part of the 256 CUs, so running the independent
+// branches on two side streams lets the dispatcher co-schedule them.
+constexpr int kMaxEvents = 160;
+struct StreamSet {
+  bool ready = false;
+  hipStream_t side[2];
+  hipEvent_t ev[kMaxEvents];
+};
+StreamSet g_streams[16];
+
+int get_streams(StreamSet** out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    cradle_set_error("elbo_step: cannot identify the current device");
+    return CRADLE_ERR_HIP;
+  }
+  StreamSet& ss = g_streams[dev];
+  if (!ss.ready) {
+    for (int i = 0; i < 2; ++i)
+      if (hipStreamCreateWithFlags(&ss.side[i], hipStreamNonBlocking) != hipSuccess) {
+        cradle_set_error("elbo_step: side stream creation failed");
+        return CRADLE_ERR_HIP;
+      }
+    for (int i = 0; i < kMaxEvents; ++i)
+      if (hipEventCreateWithFlags(&ss.ev[i], hipEventDisableTiming) != hipSuccess) {
+        cradle_set_error("elbo_step: event creation failed");
+        return CRADLE_ERR_HIP;
+      }
+    ss.ready = true;
+  }
+  *out = &ss;
+  return CRADLE_OK;
+}
+
 struct Ctx {
-  hipStream_t s;
-  float* splitk;
+  hipStream_t st[3];  // 0 = the caller's stream (critical path), 1/2 = side streams
+  float* splitk[3];
+  hipEvent_t* ev;
+  int nev = 0;
   int rc = 0;
-  // C[M,N] = A . B(^T) with epilogue options set by the caller in p
-  void gemm(int layout, GemmParams p) {
+  hipStream_t s() const { return st[0]; }
+  // C[M,N] = A . B(^T) with epilogue options set by the caller in p, on stream q
+  void gemm(int layout, GemmParams p, int q = 0) {
     if (rc) return;
-    rc = gemm_f32(layout, p, splitk, kSplitKFloats, s);
+    rc = gemm_f32(layout, p, splitk[q], kSplitKFloats, st[q]);
+  }
+  // everything enqueued on stream `dst` from now on waits for what `src` holds so far
+  void after(int dst, int src) {
+    if (rc) return;
+    if (nev >= kMaxEvents) {
+      cradle_set_error("elbo_step: out of fork/join events");
+      rc = CRADLE_ERR_HIP;
+      return;
+    }
+    hipEvent_t e = ev[nev++];
+    if (hipEventRecord(e, st[src]) != hipSuccess || hipStreamWaitEvent(st[dst], e, 0) != hipSuccess) {
+      cradle_set_error("elbo_step: event record/wait failed");
+      rc = CRADLE_ERR_HIP;
+    }
   }
 };
 
@@ -231,53 +286,62 @@ GemmParams gp(const float* A, int64_t lda, const float* B, int64_t ldb, float* C
 }
 
 // Layers 1..n-1 of a ResidualMLP (mlp.py:111-119): y_k = LeakyReLU(y_{k-1} W_k^T + b_k) + y_{k-1}.
-void trunk_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, float* const* y, float* const* r) {
+void trunk_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, float* const* y, float* const* r, int q = 0) {
   for (int k = 1; k < m.n_layers; ++k) {
     GemmParams p = gp(y[k - 1], H, m.W[k], H, y[k], H, M, H, H);
     p.bias = m.b[k]; p.act = 1; p.act_out = r[k]; p.ld_act = H; p.res = y[k - 1]; p.ld_res = H;
-    c.gemm(GEMM_NT, p);
+    c.gemm(GEMM_NT, p, q);
   }
 }
 
 // Output layer forward: out = y_last W_head^T + b_head.
-void head_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, int Nout, const float* ylast, float* out) {
+void head_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, int Nout, const float* ylast, float* out, int q = 0) {
   GemmParams p = gp(ylast, H, m.W_head, H, out, Nout, M, Nout, H);
   p.bias = m.b_head;
-  c.gemm(GEMM_NT, p);
+  c.gemm(GEMM_NT, p, q);
 }
 
-// Backward through the output layer and trunk layers n-1..1.  dout: (M, Nout) gradient of the
-// output layer's result.  Writes dW_head, db_head, dW[k], db[k] (k >= 1) and returns da_0 =
-// dL/d(pre-activation of layer 0) in (M, H).
+// Backward through the output layer and trunk layers n-1..1 on stream `q`.  dout: (M, Nout)
+// gradient of the output layer's result.  Writes dW_head, db_head, dW[k], db[k] (k >= 1) and
+// returns da_0 = dL/d(pre-activation of layer 0) in (M, H).  The data-gradient chain stays on
+// `q`; each weight-gradient GEMM is forked to side stream `wq` (alternating `wq`/`wq2`) as soon
+// as its da_k exists.  Pass wq == q to keep everything on one stream.
 const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, int M, int H, int Nout,
-                            const float* dout, float* const* y, float* const* r, float* const* Gb, float* const* dab) {
+                            const float* dout, float* const* y, float* const* r, float* const* Gb, float* const* da,
+                            int q, int wq, int wq2) {
   const int n = m.n_layers;
+  int side = wq;
+  auto wgrad = [&](GemmParams p) {
+    if (side != q) c.after(side, q);
+    c.gemm(GEMM_TN, p, side);
+    side = side == wq ? wq2 : wq;
+  };
   {  // dW_head = dout^T y_last, db_head = colsum(dout)
     GemmParams p = gp(dout, Nout, y[n - 1], H, g.W_head, H, Nout, H, M);
     p.extra_col = g.b_head;
-    c.gemm(GEMM_TN, p);
+    wgrad(p);
   }
   int cur = 0;
   {  // G_{n-1} = dout W_head ; da_{n-1} = G_{n-1} * slope(r_{n-1})
     GemmParams p = gp(dout, Nout, m.W_head, H, Gb[cur], H, M, H, Nout);
-    p.dact_src = n > 1 ? r[n - 1] : y[0]; p.ld_ds = H; p.C2 = dab[cur]; p.ldc2 = H;
-    c.gemm(GEMM_NN, p);
+    p.dact_src = n > 1 ? r[n - 1] : y[0]; p.ld_ds = H; p.C2 = da[n - 1]; p.ldc2 = H;
+    c.gemm(GEMM_NN, p, q);
   }
   for (int k = n - 1; k >= 1; --k) {
     {  // dW_k = da_k^T y_{k-1}
-      GemmParams p = gp(dab[cur], H, y[k - 1], H, g.W[k], H, H, H, M);
+      GemmParams p = gp(da[k], H, y[k - 1], H, g.W[k], H, H, H, M);
       p.extra_col = g.b[k];
-      c.gemm(GEMM_TN, p);
+      wgrad(p);
     }
     {  // G_{k-1} = da_k W_k + G_k ; da_{k-1} = G_{k-1} * slope(r_{k-1})   (r_0 = y_0)
-      GemmParams p = gp(dab[cur], H, m.W[k], H, Gb[cur ^ 1], H, M, H, H);
+      GemmParams p = gp(da[k], H, m.W[k], H, Gb[cur ^ 1], H, M, H, H);
       p.res = Gb[cur]; p.ld_res = H;
-      p.dact_src = k - 1 >= 1 ? r[k - 1] : y[0]; p.ld_ds = H; p.C2 = dab[cur ^ 1]; p.ldc2 = H;
-      c.gemm(GEMM_NN, p);
+      p.dact_src = k - 1 >= 1 ? r[k - 1] : y[0]; p.ld_ds = H; p.C2 = da[k - 1]; p.ldc2 = H;
+      c.gemm(GEMM_NN, p, q);
     }
     cur ^= 1;
   }
-  return dab[cur];
+  return da[0];
 }
 
 __global__ void fill_kernel(float* p, int64_t n, float v) {
@@ -337,20 +401,48 @@ int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
                    (long long)d.workspace_bytes, (long long)need);
   const int P = d.P, N = d.N, T = d.T, L = d.L, Q = d.Q, G = d.G, He = d.He, Hm = d.Hm, Hd = d.Hd;
   const int PP = 2 * P, PN = P * N, PT = PP * T;
-  Ctx c{s, w.splitk};
+  StreamSet* ss = nullptr;
+  rc = get_streams(&ss);
+  if (rc) return rc;
+  Ctx c;
+  c.st[0] = s; c.st[1] = ss->side[0]; c.st[2] = ss->side[1];
+  for (int i = 0; i < 3; ++i) c.splitk[i] = w.splitk[i];
+  c.ev = ss->ev;
+  hipStream_t s1 = c.st[1], s2 = c.st[2];
 #define STEP(call)        \
   do {                    \
     rc = (call);          \
     if (rc) return rc;    \
+    if (c.rc) return c.rc; \
   } while (0)
 
-  // ------------------------------------------------------------------ preparation
+  // ================================================================== forward
+  // stream 1: log-standardise X and cfX, x Wx^T.   stream 2: q(qc_E) and the per-gene constants.
+  // stream 0 (caller's): dosage plan, q(M), q(E|M), gathers -- then joins both.
+  c.after(1, 0);
+  c.after(2, 0);
+  const float* Wenc0 = d.enc.W[0];
+  const int64_t ldenc = (int64_t)G + 2 * L;
+  STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s1));
+  c.gemm(GEMM_NT, gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G), 1);  // x Wx^T, X and cfX
+
+  STEP(cradle_nb_gene_consts(d.log_concentration, w.gene_consts, G, s2));
+  hipLaunchKernelGGL(fill_kernel, dim3((Q * L + 255) / 256), dim3(256), 0, s2, w.ones_q, (int64_t)Q * L, 1.0f);
+  {  // q(qc_E): constant input ones(Q, L)
+    GemmParams p = gp(w.ones_q, L, d.qce.W[0], L, w.yq[0], Hm, Q, Hm, L);
+    p.bias = d.qce.b[0]; p.act = 1;
+    c.gemm(GEMM_NT, p, 2);
+  }
+  trunk_fwd(c, d.qce, Q, Hm, w.yq, w.rq, 2);
+  head_fwd(c, d.qce, Q, Hm, 2 * L, w.yq[d.qce.n_layers - 1], w.headsq, 2);
+  if (c.rc) return c.rc;
+  STEP(qce_fwd(w.headsq, d.eps_qc_E, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.Sq, w.qsum, PP, P, Q, L, s2));
+  c.gemm(GEMM_NT, gp(w.qcE, L, Wenc0 + G + L, ldenc, w.vq, He, PP * Q, He, L), 2);  // qc_E Wqc^T
+  const float* Wd0 = d.dec.W[0];
+  c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L), 2);        // bad-variant shift per particle
+
   STEP(build_dosage_plan(d.D, N, T, w.plan, s));
   STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, s));
-  STEP(cradle_nb_gene_consts(d.log_concentration, w.gene_consts, G, s));
-  STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s));
-
-  // ------------------------------------------------------------------ q(M), q(E|M): both guide passes at once
   STEP(mask_fwd(d.q_mask_logits, d.u_mask, d.p_mask_probs, d.temperature, w.mask, w.soft, w.Smask, PP, T, L, s));
   STEP(transpose_cols(d.emb.W[0], L + T, Hm, L, T, w.W0tT, s));
   {  // layer 0: LeakyReLU(mask Wm^T + W_onehot[:, t] + b)
@@ -362,37 +454,21 @@ int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
   head_fwd(c, d.emb, PT, Hm, 2 * L, w.yE[d.emb.n_layers - 1], w.headsE);
   if (c.rc) return c.rc;
   STEP(gaussE_fwd(w.headsE, d.eps_E, w.mask, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.ME, w.SE, PP, T, L, s));
-
-  // ------------------------------------------------------------------ q(qc_E): constant input ones(Q, L)
-  hipLaunchKernelGGL(fill_kernel, dim3((Q * L + 255) / 256), dim3(256), 0, s, w.ones_q, (int64_t)Q * L, 1.0f);
-  {
-    GemmParams p = gp(w.ones_q, L, d.qce.W[0], L, w.yq[0], Hm, Q, Hm, L);
-    p.bias = d.qce.b[0]; p.act = 1;
-    c.gemm(GEMM_NT, p);
-  }
-  trunk_fwd(c, d.qce, Q, Hm, w.yq, w.rq);
-  head_fwd(c, d.qce, Q, Hm, 2 * L, w.yq[d.qce.n_layers - 1], w.headsq);
-  if (c.rc) return c.rc;
-  STEP(qce_fwd(w.headsq, d.eps_qc_E, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.Sq, w.qsum, PP, P, Q, L, s));
-
-  // ------------------------------------------------------------------ basal encoder
-  const float* Wenc0 = d.enc.W[0];
-  const int64_t ldenc = (int64_t)G + 2 * L;
-  c.gemm(GEMM_NT, gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G));                      // x Wx^T, X and cfX
   STEP(gather_offsets(w.ME, w.plan, w.zoff + L, 2 * L, w.offB, L, PP, P, N, T, L, s));     // D @ (mask*E)
   c.gemm(GEMM_NT, gp(w.zoff + L, 2 * L, Wenc0 + G, ldenc, w.offW, He, PN, He, L));         // main pass offsets
   c.gemm(GEMM_NT, gp(w.offB, L, Wenc0 + G, ldenc, w.offW + (int64_t)PN * He, He, PN, He, L));  // cf pass offsets
-  c.gemm(GEMM_NT, gp(w.qcE, L, Wenc0 + G + L, ldenc, w.vq, He, PP * Q, He, L));            // qc_E Wqc^T
+  c.after(0, 1);
+  c.after(0, 2);
   if (c.rc) return c.rc;
+
+  // basal encoder (three variants), z_basal, counterfactual KL
   STEP(enc_combine_fwd(w.xW, w.offW, w.vq, d.enc.b[0], d.qc, w.yz[0], P, N, Q, He, s));
   trunk_fwd(c, d.enc, 3 * PN, He, w.yz, w.rz);
   head_fwd(c, d.enc, 3 * PN, He, 2 * L, w.yz[d.enc.n_layers - 1], w.headsz);
   if (c.rc) return c.rc;
   STEP(zhead_fwd(w.headsz, d.eps_z, w.hascf, d.beta, w.zoff, 2 * L, w.sdz, w.ltz, w.klrow, w.dheadsz, P, N, L, s));
 
-  // ------------------------------------------------------------------ decoder, live variant per cell
-  const float* Wd0 = d.dec.W[0];
-  c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L));  // bad-variant shift per particle
+  // decoder, live variant per cell
   {
     GemmParams p = gp(w.zoff, 2 * L, Wd0, 3 * L, w.yd[0], Hd, PN, Hd, 2 * L);
     p.bias = d.dec.b[0]; p.act = 1; p.rowbias = w.wq; p.ld_rb = Hd; p.rb_mode = 1; p.rb_n = N;
@@ -415,51 +491,58 @@ int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
   if (!d.compute_grads) return CRADLE_OK;
 
   // ================================================================== backward
+  // The data-gradient chain runs on stream 0; every weight-gradient GEMM is forked to a side
+  // stream as soon as its inputs exist.  All streams are joined before returning.
   // decoder: logits now hold d loss / d logits
-  const float* da0d = head_trunk_bwd(c, d.dec, d.d_dec, PN, Hd, G, w.logits, w.yd, w.rd, w.Gd, w.dad);
+  const float* da0d = head_trunk_bwd(c, d.dec, d.d_dec, PN, Hd, G, w.logits, w.yd, w.rd, w.Gd, w.dad, 0, 1, 2);
   if (c.rc) return c.rc;
+  c.after(2, 0);
   {  // dW0[:, :2L] = da0^T [z | off], db0
     GemmParams p = gp(da0d, Hd, w.zoff, 2 * L, d.d_dec.W[0], 3 * L, Hd, 2 * L, PN);
     p.extra_col = d.d_dec.b[0];
-    c.gemm(GEMM_TN, p);
+    c.gemm(GEMM_TN, p, 2);
   }
   STEP(weighted_rowgroup_sum(da0d, w.cp.live, P, N, Hd, w.dwq, s));
-  c.gemm(GEMM_TN, gp(w.dwq, Hd, w.qsum, L, d.d_dec.W[0] + 2 * L, 3 * L, Hd, L, P));   // dW0[:, 2L:]
-  c.gemm(GEMM_NN, gp(w.dwq, Hd, Wd0 + 2 * L, 3 * L, w.dq_dec, L, P, L, Hd));          // d qsum
-  c.gemm(GEMM_NN, gp(da0d, Hd, Wd0, 3 * L, w.dzoff, 2 * L, PN, 2 * L, Hd));           // [dz | doff]
+  c.after(2, 0);
+  c.gemm(GEMM_TN, gp(w.dwq, Hd, w.qsum, L, d.d_dec.W[0] + 2 * L, 3 * L, Hd, L, P), 2);  // dW0[:, 2L:]
+  c.gemm(GEMM_NN, gp(w.dwq, Hd, Wd0 + 2 * L, 3 * L, w.dq_dec, L, P, L, Hd));            // d qsum
+  c.gemm(GEMM_NN, gp(da0d, Hd, Wd0, 3 * L, w.dzoff, 2 * L, PN, 2 * L, Hd));             // [dz | doff]
   if (c.rc) return c.rc;
 
   // basal encoder
   STEP(zhead_bwd(w.headsz, d.eps_z, w.zoff, 2 * L, w.sdz, w.dzoff, 2 * L, w.dheadsz, P, N, L, s));
-  const float* dpre = head_trunk_bwd(c, d.enc, d.d_enc, 3 * PN, He, 2 * L, w.dheadsz, w.yz, w.rz, w.Gz, w.daz);
+  const float* dpre = head_trunk_bwd(c, d.enc, d.d_enc, 3 * PN, He, 2 * L, w.dheadsz, w.yz, w.rz, w.Gz, w.daz, 0, 1, 2);
   if (c.rc) return c.rc;
   STEP(enc_combine_bwd(dpre, d.qc, w.doffW, w.dxW, w.dvq, P, N, Q, He, s));
   float* dWenc0 = d.d_enc.W[0];
+  c.after(1, 0);
+  c.after(2, 0);
   {  // dWx = dxW^T logstd([X; cfX]); db0 = colsum(dxW)
     GemmParams p = gp(w.dxW, He, w.xn, G, dWenc0, ldenc, He, G, 2 * N);
     p.extra_col = d.d_enc.b[0];
-    c.gemm(GEMM_TN, p);
+    c.gemm(GEMM_TN, p, 1);
   }
   // dWoff = doffW^T [offA; offB]  (two row blocks of one sum: second call accumulates)
-  c.gemm(GEMM_TN, gp(w.doffW, He, w.zoff + L, 2 * L, dWenc0 + G, ldenc, He, L, PN));
+  c.gemm(GEMM_TN, gp(w.doffW, He, w.zoff + L, 2 * L, dWenc0 + G, ldenc, He, L, PN), 2);
   {
     GemmParams p = gp(w.doffW + (int64_t)PN * He, He, w.offB, L, dWenc0 + G, ldenc, He, L, PN);
     p.beta = 1.0f;
-    c.gemm(GEMM_TN, p);
+    c.gemm(GEMM_TN, p, 2);
   }
-  c.gemm(GEMM_TN, gp(w.dvq, He, w.qcE, L, dWenc0 + G + L, ldenc, He, L, PP * Q));      // dWqc
-  c.gemm(GEMM_NN, gp(w.doffW, He, Wenc0 + G, ldenc, w.doffenc, L, 2 * PN, L, He));     // d offsets via encoder
-  c.gemm(GEMM_NN, gp(w.dvq, He, Wenc0 + G + L, ldenc, w.dq_enc, L, PP * Q, L, He));    // d qc_E via encoder
+  c.gemm(GEMM_TN, gp(w.dvq, He, w.qcE, L, dWenc0 + G + L, ldenc, He, L, PP * Q), 2);      // dWqc
+  c.gemm(GEMM_NN, gp(w.doffW, He, Wenc0 + G, ldenc, w.doffenc, L, 2 * PN, L, He));        // d offsets via encoder
+  c.gemm(GEMM_NN, gp(w.dvq, He, Wenc0 + G + L, ldenc, w.dq_enc, L, PP * Q, L, He));       // d qc_E via encoder
   if (c.rc) return c.rc;
 
-  // q(qc_E)
+  // q(qc_E): whole backward on stream 2 (tiny, off the critical path)
+  c.after(2, 0);
   STEP(qce_bwd(w.headsq, d.eps_qc_E, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.dq_enc, w.dq_dec, w.cp.coefQ,
-               w.dheadsq, PP, P, Q, L, s));
-  const float* da0q = head_trunk_bwd(c, d.qce, d.d_qce, Q, Hm, 2 * L, w.dheadsq, w.yq, w.rq, w.Gq, w.daq);
+               w.dheadsq, PP, P, Q, L, s2));
+  const float* da0q = head_trunk_bwd(c, d.qce, d.d_qce, Q, Hm, 2 * L, w.dheadsq, w.yq, w.rq, w.Gq, w.daq, 2, 2, 2);
   {
     GemmParams p = gp(da0q, Hm, w.ones_q, L, d.d_qce.W[0], L, Hm, L, Q);
     p.extra_col = d.d_qce.b[0];
-    c.gemm(GEMM_TN, p);
+    c.gemm(GEMM_TN, p, 2);
   }
   if (c.rc) return c.rc;
 
@@ -467,18 +550,22 @@ int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
   STEP(scatter_offsets(w.plan, w.dzoff + L, 2 * L, w.doffenc, L, w.doffenc + (int64_t)PN * L, L, w.dME, PP, P, N, T, L, s));
   STEP(gaussE_bwd(w.headsE, d.eps_E, w.mask, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.dME, w.cp.coefT, w.dheadsE, w.dmaskME,
                   PP, P, T, L, s));
-  const float* da0E = head_trunk_bwd(c, d.emb, d.d_emb, PT, Hm, 2 * L, w.dheadsE, w.yE, w.rE, w.GE, w.daE);
+  const float* da0E = head_trunk_bwd(c, d.emb, d.d_emb, PT, Hm, 2 * L, w.dheadsE, w.yE, w.rE, w.GE, w.daE, 0, 1, 1);
   if (c.rc) return c.rc;
+  c.after(1, 0);
   {  // dW0[:, :L] = da0^T mask, db0
     GemmParams p = gp(da0E, Hm, w.mask, L, d.d_emb.W[0], L + T, Hm, L, PT);
     p.extra_col = d.d_emb.b[0];
-    c.gemm(GEMM_TN, p);
+    c.gemm(GEMM_TN, p, 1);
   }
-  STEP(sum_over_groups_to_cols(da0E, PP, T, Hm, d.d_emb.W[0], L + T, L, s));            // dW0[:, L:]
-  c.gemm(GEMM_NN, gp(da0E, Hm, d.emb.W[0], L + T, w.dmask_enc, L, PT, L, Hm));           // d mask via encoder input
+  STEP(sum_over_groups_to_cols(da0E, PP, T, Hm, d.d_emb.W[0], L + T, L, s1));            // dW0[:, L:]
+  c.gemm(GEMM_NN, gp(da0E, Hm, d.emb.W[0], L + T, w.dmask_enc, L, PT, L, Hm));            // d mask via encoder input
   if (c.rc) return c.rc;
   STEP(mask_bwd(d.q_mask_logits, d.p_mask_probs, d.temperature, w.mask, w.soft, w.dmaskME, w.dmask_enc, w.cp.coefT,
                 d.d_q_mask_logits, PP, P, T, L, s));
+  c.after(0, 1);
+  c.after(0, 2);
+  if (c.rc) return c.rc;
 #undef STEP
   return CRADLE_OK;
 }

@@ -37,7 +37,8 @@ PROTOTYPES = {
     "cradle_nb_particle_split": (i32, [i32, i32]),
     "cradle_gemm_f32": (i32, [ctypes.c_void_p, c_float_p, i64, c_stream]),
     "cradle_gemm_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
-    "cradle_gemm_tune": (None, [i32, i32, i32, i32, i32]),
+    "cradle_gemm_tune": (None, [i32, i32, i32, i32, i32, i32]),
+    "cradle_gemm_f32_repeat": (i32, [ctypes.c_void_p, c_float_p, i64, i32, c_stream]),
     "cradle_elbo_step_workspace_bytes": (i64, [ctypes.c_void_p]),
     "cradle_elbo_step": (i32, [ctypes.c_void_p, c_stream]),
     "cradle_adam_step": (

@@ -106,9 +106,10 @@ def gemm(
     residual: Optional[torch.Tensor] = None, dact_src: Optional[torch.Tensor] = None,
     out2: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None, rowbias_mode: int = 0,
     rowbias_n: int = 0, rowscale: Optional[torch.Tensor] = None, extra_col: Optional[torch.Tensor] = None,
-    workspace: Optional[torch.Tensor] = None,
+    workspace: Optional[torch.Tensor] = None, repeat: int = 1,
 ) -> torch.Tensor:
-    """fp32 MFMA GEMM with the fused epilogue of ``cradle_gemm_f32`` (see the header)."""
+    """fp32 MFMA GEMM with the fused epilogue of ``cradle_gemm_f32`` (see the header).
+    ``repeat`` > 1 relaunches the same GEMM from C (benchmarking aid)."""
     if layout == NT:
         (M, K), (N, K2) = A.shape, B.shape
     elif layout == NN:
@@ -149,5 +150,8 @@ def gemm(
     ws_ptr, ws_n = (hip.ptr(workspace), workspace.numel()) if workspace is not None else (None, 0)
     import ctypes
 
-    hip.check(hip.load().cradle_gemm_f32(ctypes.byref(d), ws_ptr, ws_n, hip.stream()), "gemm_f32")
+    if repeat > 1:
+        hip.check(hip.load().cradle_gemm_f32_repeat(ctypes.byref(d), ws_ptr, ws_n, repeat, hip.stream()), "gemm_f32")
+    else:
+        hip.check(hip.load().cradle_gemm_f32(ctypes.byref(d), ws_ptr, ws_n, hip.stream()), "gemm_f32")
     return out

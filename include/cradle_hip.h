@@ -109,8 +109,11 @@ typedef struct cradle_gemm_desc {
 int cradle_gemm_f32(const cradle_gemm_desc* desc, float* workspace, int64_t workspace_floats, cradle_stream_t stream);
 int64_t cradle_gemm_workspace_floats(int layout, int M, int N, int K, int extra_col);
 /* tuning hook for tools/tune_gemm.py: force the tile (tm, tn in {1,2} x 64), K step (16/32),
- * prefetch depth and K split; -1 = automatic.  Not used on the product path. */
-void cradle_gemm_tune(int tm, int tn, int bk, int depth, int splitk);
+ * prefetch depth, K wave-groups per workgroup (1/2) and K split; -1 = automatic.  Not used on
+ * the product path. */
+void cradle_gemm_tune(int tm, int tn, int bk, int depth, int wk, int splitk);
+int cradle_gemm_f32_repeat(const cradle_gemm_desc* desc, float* workspace, int64_t workspace_floats, int repeat,
+                           cradle_stream_t stream);
 
 /* ---- The fused ELBO step ---------------------------------------------------------------
  * Forward + backward of PerturbationPlatedELBOLossModule.loss

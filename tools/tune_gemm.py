@@ -8,17 +8,18 @@ dev = "cuda:0"
 lib = hip.load()
 
 
-def timeit(fn, iters=20):
-    for _ in range(3):
-        fn()
+REP = 20
+
+
+def timeit(fn):
+    fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    fn()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+    return e0.elapsed_time(e1) / REP * 1e-3
 
 
 shapes = [
@@ -32,7 +33,7 @@ shapes = [
     (ops.NT, 2560, 400, 200, "offW fwd"), (ops.NN, 5120, 200, 400, "offW dgrad"), (ops.TN, 400, 200, 2560, "offW wgrad"),
     (ops.NT, 1, 400, 400, "qc enc"),
 ]
-cfgs = [(2, 2, 16, 2), (2, 2, 16, 4), (1, 2, 16, 4), (1, 2, 32, 2), (1, 1, 16, 2), (1, 1, 16, 4), (1, 1, 16, 6), (1, 1, 32, 2), (1, 1, 32, 4)]
+cfgs = [(2, 2, 16, 2, 1), (1, 1, 16, 2, 1), (1, 1, 16, 4, 1), (1, 1, 32, 2, 1), (1, 1, 32, 2, 2), (1, 1, 32, 4, 2), (1, 2, 32, 2, 2), (2, 2, 32, 2, 2)]
 splits = [1, 2, 4, 8, 16]
 for layout, M, N, K, what in shapes:
     if layout == ops.NT:
@@ -43,16 +44,16 @@ for layout, M, N, K, what in shapes:
         A, B = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev)
     out = torch.empty(M, N, device=dev)
     ws = torch.empty(min(lib.cradle_gemm_workspace_floats(layout, M, N, K, 0), 1 << 26), device=dev)
-    lib.cradle_gemm_tune(-1, -1, -1, -1, -1)
-    t_auto = timeit(lambda: ops.gemm(layout, A, B, out=out, workspace=ws))
+    lib.cradle_gemm_tune(-1, -1, -1, -1, -1, -1)
+    t_auto = timeit(lambda: ops.gemm(layout, A, B, out=out, workspace=ws, repeat=REP))
     res = []
-    for tm, tn, bk, dp in cfgs:
+    for tm, tn, bk, dp, wk in cfgs:
         for sk in splits:
             if sk > max(1, (K + bk - 1) // bk // 2):
                 continue
-            lib.cradle_gemm_tune(tm, tn, bk, dp, sk)
-            res.append((timeit(lambda: ops.gemm(layout, A, B, out=out, workspace=ws)), tm, tn, f"{bk}d{dp}", sk))
-    lib.cradle_gemm_tune(-1, -1, -1, -1, -1)
+            lib.cradle_gemm_tune(tm, tn, bk, dp, wk, sk)
+            res.append((timeit(lambda: ops.gemm(layout, A, B, out=out, workspace=ws, repeat=REP)), tm, tn, f"{bk}d{dp}w{wk}", sk))
+    lib.cradle_gemm_tune(-1, -1, -1, -1, -1, -1)
     res.sort()
     fl = 2.0 * M * N * K
     best = " | ".join(f"{t*1e6:6.1f}us t{tm}{tn} bk{bk} s{sk}" for t, tm, tn, bk, sk in res[:4])
