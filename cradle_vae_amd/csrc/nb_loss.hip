@@ -103,10 +103,10 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
     float se = 0.f;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-      cur[j].x = __expf(cur[j].x - mx);
-      cur[j].y = __expf(cur[j].y - mx);
-      cur[j].z = __expf(cur[j].z - mx);
-      cur[j].w = __expf(cur[j].w - mx);
+      cur[j].x = fast_exp(cur[j].x - mx);
+      cur[j].y = fast_exp(cur[j].y - mx);
+      cur[j].z = fast_exp(cur[j].z - mx);
+      cur[j].w = fast_exp(cur[j].w - mx);
       se += (cur[j].x + cur[j].y) + (cur[j].z + cur[j].w);
     }
     se = block_sum<NT>(se, reinterpret_cast<float*>(slot + 1));
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
 }
 
 constexpr int kNbMaxGenes = 1024 * 4 * 4;
+static int g_nb_tune_nt = -1, g_nb_tune_ps = -1;
 
 template <bool BWD>
 static int launch_nb_rows(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
@@ -223,17 +224,28 @@ static int launch_nb_rows(const float* logits, int64_t ld_logits, float* dlogits
 #define CRADLE_NB_LAUNCH(VPT, NT)                                                                       \
   hipLaunchKernelGGL((nb_rows_kernel<VPT, NT, BWD>), grid, dim3(NT), 0, stream, logits, ld_logits,      \
                      dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, dlogc_part, P, N, G, PS)
-  if (G4 <= 256 * 1) CRADLE_NB_LAUNCH(1, 256);
-  else if (G4 <= 256 * 2) CRADLE_NB_LAUNCH(2, 256);
-  else if (G4 <= 256 * 3) CRADLE_NB_LAUNCH(3, 256);
-  else if (G4 <= 256 * 4) CRADLE_NB_LAUNCH(4, 256);
-  else if (G4 <= 256 * 5) CRADLE_NB_LAUNCH(5, 256);
-  else if (G4 <= 512 * 3) CRADLE_NB_LAUNCH(3, 512);
-  else if (G4 <= 512 * 4) CRADLE_NB_LAUNCH(4, 512);
-  else if (G4 <= 1024 * 3) CRADLE_NB_LAUNCH(3, 1024);
-  else if (G4 <= 1024 * 4) CRADLE_NB_LAUNCH(4, 1024);
-  else {
-    cradle_set_error("nb_rows: n_genes=%d exceeds the supported maximum %d", G, kNbMaxGenes);
+  // thread count / values per thread: as many waves per CU as the register budget allows (all
+  // workgroups of a 512-cell batch are then resident at once); override via cradle_nb_tune
+  int nt = g_nb_tune_nt;
+  if (nt <= 0) nt = G4 <= 256 * 5 ? 256 : (G4 <= 512 * 4 ? 512 : 1024);  // measured: tools/bench_nb.py
+  const int vpt = (G4 + nt - 1) / nt;
+  bool launched = true;
+  if (nt == 256 && vpt == 1) CRADLE_NB_LAUNCH(1, 256);
+  else if (nt == 256 && vpt == 2) CRADLE_NB_LAUNCH(2, 256);
+  else if (nt == 256 && vpt == 3) CRADLE_NB_LAUNCH(3, 256);
+  else if (nt == 256 && vpt == 4) CRADLE_NB_LAUNCH(4, 256);
+  else if (nt == 256 && vpt == 5) CRADLE_NB_LAUNCH(5, 256);
+  else if (nt == 512 && vpt == 1) CRADLE_NB_LAUNCH(1, 512);
+  else if (nt == 512 && vpt == 2) CRADLE_NB_LAUNCH(2, 512);
+  else if (nt == 512 && vpt == 3) CRADLE_NB_LAUNCH(3, 512);
+  else if (nt == 512 && vpt == 4) CRADLE_NB_LAUNCH(4, 512);
+  else if (nt == 1024 && vpt == 1) CRADLE_NB_LAUNCH(1, 1024);
+  else if (nt == 1024 && vpt == 2) CRADLE_NB_LAUNCH(2, 1024);
+  else if (nt == 1024 && vpt == 3) CRADLE_NB_LAUNCH(3, 1024);
+  else if (nt == 1024 && vpt == 4) CRADLE_NB_LAUNCH(4, 1024);
+  else launched = false;
+  if (!launched) {
+    cradle_set_error("nb_rows: n_genes=%d not supported with %d threads (maximum %d genes)", G, nt, kNbMaxGenes);
     return CRADLE_ERR_UNSUPPORTED;
   }
 #undef CRADLE_NB_LAUNCH
@@ -267,7 +279,14 @@ int cradle_nb_gene_consts(const float* log_c, float* gene_consts, int G, hipStre
   return CRADLE_OK;
 }
 
+// tuning hook (tools/bench_nb.py): threads per workgroup (256/512/1024) and particle split; -1 = auto
+void cradle_nb_tune(int threads, int particle_split) {
+  cradle::g_nb_tune_nt = threads;
+  cradle::g_nb_tune_ps = particle_split;
+}
+
 int cradle_nb_particle_split(int P, int N) {
+  if (cradle::g_nb_tune_ps > 0) return cradle::g_nb_tune_ps < P ? cradle::g_nb_tune_ps : P;
   // enough workgroups to cover the chip (256 CUs x 2) without splitting a cell's particles
   // more than needed: each split re-reads X[n] and redoes the per-cell lgamma terms
   int ps = 1;

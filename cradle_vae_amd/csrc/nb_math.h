@@ -16,14 +16,19 @@ constexpr float kMuEps = 1e-4f;    // mlp.py:161
 constexpr float kRateMin = 1e-6f;  // mlp.py:163
 
 __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+// natural log / exp on the bare v_log_f32 / v_exp_f32 (1 ulp, no denormal fix-up code): every
+// argument here is a normal float (rates >= 1e-6, 1 + rate >= 1, counts >= 1), and an
+// exponent argument far below zero may flush to 0, which is its correct limit in a softmax
+__device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.6931471805599453f; }
+__device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
 
 // log(1+r) with relative accuracy for small |r| (r > -1).
 __device__ __forceinline__ float log1p_acc(float r) {
+  // log(u) of the rounded u = fl(1+r) plus the first-order correction for the rounding error d:
+  // log(1+r) = log(u) + log1p(d/u) ~ log(u) + d/u  (|d/u| <= 2^-24)
   const float u = 1.0f + r;
-  const float d = r - (u - 1.0f);  // rounding error of 1+r
-  const float big = __logf(u) + d * fast_rcp(u);
-  const float small = r * fmaf(r, fmaf(r, fmaf(r, -0.25f, 1.0f / 3.0f), -0.5f), 1.0f);
-  return fabsf(r) < 0.0078125f ? small : big;
+  const float d = r - (u - 1.0f);
+  return fast_log(u) + d * fast_rcp(u);
 }
 
 // L(x,c) and (BWD) psi(c+x) - psi(c).  x must be a non-negative integer-valued float (the
@@ -49,14 +54,14 @@ __device__ __forceinline__ float nb_lgamma_term(float x, float c, float lgc, flo
       if (BWD) dp += fast_rcp(c + 3.0f);
     }
     dpsi = dp;
-    return __logf(prod);
+    return fast_log(prod);
   }
   // Stirling difference lgamma(a) - lgamma(b), a = c+x, b = x+1 (both >= 5), arranged so that
   // nothing large cancels: (a-.5)log(a) - (b-.5)log(b) = (a-.5)log1p((c-1)/b) + (c-1)log(b)
   const float a = c + x, b = x + 1.0f;
   const float ia = fast_rcp(a), ib = fast_rcp(b);
   const float cm1 = c - 1.0f;
-  const float lb = __logf(b);
+  const float lb = fast_log(b);
   const float ia2 = ia * ia, ib2 = ib * ib;
   float A = (a - 0.5f) * log1p_acc(cm1 * ib) + cm1 * (lb - 1.0f);
   A += (ia - ib) * (1.0f / 12.0f) - (ia * ia2 - ib * ib2) * (1.0f / 360.0f) +
@@ -77,7 +82,7 @@ __device__ __forceinline__ float nb_main_term(float mu, float x, float c, float&
   const float rate0 = c * fast_rcp(m);
   const bool clamped = rate0 < kRateMin;  // torch.clamp(min=1e-6): gradient passes where rate0 >= min
   const float rate = clamped ? kRateMin : rate0;
-  const float lr = __logf(rate);
+  const float lr = fast_log(rate);
   const float l1p = log1p_acc(rate);
   if (BWD) {
     const float rmc = fast_rcp(m + c);

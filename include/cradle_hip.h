@@ -75,6 +75,8 @@ int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlo
                               cradle_stream_t stream);
 int64_t cradle_nb_workspace_floats(int P, int N, int G);
 int cradle_nb_particle_split(int P, int N);
+/* tuning hook for tools/bench_nb.py: threads per workgroup (256/512/1024), particle split; -1 = auto */
+void cradle_nb_tune(int threads, int particle_split);
 
 /* ---- K6: fp32 matrix-core GEMM with fused MLP epilogues ---------------------------------
  * Replaces torch.nn.Linear (+ LeakyReLU + residual) of cradle_vae/models/utils/mlp.py:76-80,

@@ -15,7 +15,7 @@ X = torch.poisson(torch.exp(-1 + 1.5 * torch.randn(G, device=dev)).expand(N, G).
 lib = X.sum(1) + 1
 gc = ops.nb_gene_consts(torch.zeros(G, device=dev))
 grow = torch.full((P * N,), -1.0 / (P * N), device=dev)
-ws = torch.empty(N * G * 4, device=dev)
+ws = torch.empty(N * G * 8, device=dev)
 dlc = torch.zeros(G, device=dev)
 scr = logits.clone()
 
@@ -33,6 +33,16 @@ def timeit(fn, iters=50):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+from cradle_vae_amd import hip
+for nt in (256, 512, 1024):
+    for ps in (1, 2, 5):
+        if G // 4 > nt * (5 if nt == 256 else 4):
+            continue
+        hip.load().cradle_nb_tune(nt, ps)
+        tf = timeit(lambda: ops.nb_logprob_fwd(logits, X, lib, gc, P))
+        tb = timeit(lambda: ops.nb_logprob_fwd_bwd(logits, X, lib, gc, grow, P, workspace=ws))
+        print(f"threads {nt:4d} split {ps}: fwd {tf*1e6:7.1f} us  fwd+bwd(+colsum) {tb*1e6:7.1f} us")
+hip.load().cradle_nb_tune(-1, -1)
 t_f = timeit(lambda: ops.nb_logprob_fwd(logits, X, lib, gc, P))
 t_b = timeit(lambda: ops.nb_logprob_fwd_bwd(logits, X, lib, gc, grow, P, workspace=ws))
 fwd_bytes = 4 * G * (P * N + N)
