@@ -1,0 +1,138 @@
+"""Model-based average treatment effects -- mirror of the reference's
+``estimate_model_average_treatment_effect`` (cradle_vae/analysis/average_treatment_effects.py:78-203).
+
+The reference walks the alternative perturbations one by one, each with its own decoder call
+and count draw (:178-195).  Here the control and every alternative perturbation of a particle
+chunk go through ONE decoder GEMM chain, and one launch of the sampler kernel
+(``cradle_nb_sample_accumulate``, K9) draws the counts, applies the perturb-seq
+normalisation and adds them to the per-perturbation sums without materialising the draws.
+
+Particle chunks are independent given the seed, so with ``torch.distributed`` initialised
+they are dealt round-robin to the ranks and the sums meet in one all-reduce.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Literal, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops, parallel
+
+MAX_ROWS_PER_LAUNCH = 1 << 16  # decoder rows (particles x conditions) per GEMM chain / sampler launch
+
+
+def _chunk_generator(device, seed: int, chunk_idx: int) -> torch.Generator:
+    g = torch.Generator(device=device)
+    g.manual_seed((seed * 1000003 + chunk_idx) & (2**63 - 1))
+    return g
+
+
+def _latent_offsets(D: torch.Tensor, EM: torch.Tensor) -> torch.Tensor:
+    """D (C, T) @ EM (c, T, L) -> (c, C, L) through the non-zero pattern of D (<= a few guides
+    per perturbation: model.py:115 with one-hot / few-hot dosages)."""
+    nnz = int((D != 0).sum(dim=1).max().item()) if D.numel() else 0
+    if nnz == 0:
+        return torch.zeros((EM.shape[0], D.shape[0], EM.shape[2]), device=EM.device, dtype=EM.dtype)
+    if nnz > 8:
+        return torch.matmul(D, EM)
+    w, idx = torch.topk(D.abs(), nnz, dim=1)  # (C, nnz): positions of the non-zeros (ties at 0 carry weight 0)
+    w = torch.gather(D, 1, idx)
+    out = None
+    for k in range(nnz):
+        term = EM[:, idx[:, k], :] * w[:, k].reshape(1, -1, 1)
+        out = term if out is None else out + term
+    return out
+
+
+@torch.no_grad()
+def estimate_model_average_treatment_effect(
+    model: torch.nn.Module,
+    guide: torch.nn.Module,
+    dosages_alt: torch.Tensor,
+    dosages_control: torch.Tensor,
+    quality: torch.Tensor,
+    n_particles: int,
+    method: Literal["mean", "perturbseq"],
+    condition_values: Optional[Dict[str, torch.Tensor]] = None,
+    batch_size: int = 500,
+    dosage_independent_variables: Optional[List[str]] = None,
+    seed: int = 0,
+    *,
+    sampler: Literal["nb", "mean"] = "nb",
+    noise_chunks: Optional[Sequence[Dict[str, torch.Tensor]]] = None,
+) -> np.ndarray:
+    """-> (n_alt, n_phenos) numpy array: mean over particles of (transformed) x_good under
+    each alternative dosage minus the same under the control dosage.
+
+    ``sampler="mean"`` replaces the count draw by the distribution mean and ``noise_chunks``
+    (per chunk: u_mask, eps_E, eps_qc_E, z_control (c,1,L), z_alt (n_alt,c,1,L)) injects the
+    latent draws: the deterministic form the golden fixture pins against the reference.
+    """
+    assert method in ("mean", "perturbseq"), "Method must be one of ['mean', 'perturbseq']"  # :94-95
+    if model.sum_mode:
+        raise NotImplementedError("sum_mode=True decoders are not on the HIP path (no shipped config uses them)")
+    cv = dict(condition_values) if condition_values is not None else {}
+    device = next(model.parameters()).device
+    D_alt = dosages_alt.to(device=device, dtype=torch.float32)
+    D_ctl = dosages_control.to(device=device, dtype=torch.float32)
+    if D_ctl.shape[0] != 1:
+        raise ValueError("dosages_control must have exactly one row")
+    if "library_size" not in cv:
+        raise KeyError("condition_values['library_size'] is required by the library_nb decoder (model.py:128)")
+    lib = cv["library_size"].to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+    if lib.numel() != 1:
+        raise ValueError("the ATE estimator takes one library size shared by all conditions (eval.py:95)")
+    D_all = torch.cat([D_ctl, D_alt], dim=0)
+    C, L, G = D_all.shape[0], model.n_latent, model.n_phenos
+    share_z = dosage_independent_variables is not None and "z_basal" in dosage_independent_variables
+    gene_consts = ops.nb_gene_consts(model.decoder.log_concentration.detach())
+    sums = torch.zeros((C, G), device=device, dtype=torch.float32)
+
+    world, rank = parallel.world_and_rank()
+    starts = list(range(0, n_particles, batch_size))
+    for ci in parallel.my_chunks(len(starts), world, rank):
+        i = starts[ci]
+        c = min(batch_size, n_particles - i)
+        gen = _chunk_generator(device, seed, ci)
+        if noise_chunks is not None:
+            nz = {k: v.to(device=device, dtype=torch.float32) for k, v in noise_chunks[ci].items()}
+        else:
+            T, Q = guide.n_treatments, guide.n_qc
+            nz = dict(
+                u_mask=torch.rand((c, T, L), device=device, generator=gen),
+                eps_E=torch.randn((c, T, L), device=device, generator=gen),
+                eps_qc_E=torch.randn((c, Q, L), device=device, generator=gen),
+            )
+        plated_cv = {k: v for k, v in cv.items() if k in ("mask", "E", "qc_E")}
+        _, gs = guide(n_particles=c, condition_values=plated_cv, noise=nz)  # :143-145
+        EM = gs["E"] * gs["mask"]
+        # conditions in slabs so that one decoder pass stays within MAX_ROWS_PER_LAUNCH rows
+        slab = max(1, MAX_ROWS_PER_LAUNCH // c)
+        z_shared = None
+        for s0 in range(0, C, slab):
+            s1 = min(C, s0 + slab)
+            n = s1 - s0
+            if "z_basal" in cv:
+                z = cv["z_basal"].to(device)
+                z = (z.unsqueeze(0) if z.dim() == 2 else z).expand(c, -1, -1)
+                z = z.expand(c, C, L)[:, s0:s1] if z.shape[1] == 1 else z[:, s0:s1]
+            elif "z_control" in nz:
+                zc, za = nz["z_control"], nz["z_alt"]  # (c,1,L), (n_alt,c,1,L)
+                z_all = zc.expand(c, C, L) if share_z else torch.cat([zc, za[:, :, 0, :].permute(1, 0, 2)], dim=1)
+                z = z_all[:, s0:s1]
+            elif share_z:  # :165-167: z_basal of the control call is reused for every alternative
+                if z_shared is None:
+                    z_shared = torch.randn((c, 1, L), device=device, generator=gen)
+                z = z_shared.expand(c, n, L)
+            else:  # p_z_basal = Normal(0, 1) drawn per call (model.py:82)
+                z = torch.randn((c, n, L), device=device, generator=gen)
+            off = _latent_offsets(D_all[s0:s1], EM)
+            z_good = torch.cat([z, off, torch.zeros((c, n, L), device=device)], dim=-1)  # model.py:121
+            p_x_good = model.decoder(z_good, lib)
+            call_seed = (seed * 7919 + ci) * 4099 + s0
+            ops.nb_sample_accumulate(
+                p_x_good.logits, lib, gene_consts, c, n, sums=sums[s0:s1], method=method, sampler=sampler, seed=call_seed)
+    parallel.allreduce_sum_(sums, world)
+    means = sums / n_particles  # :199-200
+    return (means[1:] - means[:1]).cpu().numpy()

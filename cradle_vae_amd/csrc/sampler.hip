@@ -1,0 +1,235 @@
+// K9: Gamma-Poisson observation sampler fused with the ATE accumulation.
+//
+// Replaces, per (perturbation, particle) row of decoder logits:
+//   cradle_vae/models/utils/mlp.py:153-166      softmax -> mu -> rate, GammaPoisson(c, rate)
+//   pyro GammaPoisson.sample (pyro-ppl 1.9.1)   rate' ~ Gamma(c, rate); x ~ Poisson(rate')   (model.py:131)
+//   cradle_vae/analysis/average_treatment_effects.py:171-176,190-195
+//       method "perturbseq": x <- log2(1e4 * x / sum_g x + 1);  X_sums[t] += sum over particles
+// One workgroup per condition (perturbation) t: every thread owns fixed genes, walks the
+// particles of that condition and keeps the running sums in registers, so the (P, T, G) sample
+// tensor of the reference is never materialised and the sum over particles is deterministic.
+// Random numbers: Philox4x32-10 keyed by (seed, stream), counter = (gene, row, draw index): the
+// result does not depend on the launch geometry.  (Bit-parity with torch's generator is
+// impossible by construction; parity tests use sampler = MEAN, moments tests the real sampler.)
+#include "common.h"
+#include "nb_math.h"
+
+namespace cradle {
+
+struct Philox {
+  uint32_t k0, k1;
+  __device__ static inline void round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+  }
+  __device__ inline uint4 operator()(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) const {
+    uint32_t a = k0, b = k1;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      round(c0, c1, c2, c3, a, b);
+      a += 0x9E3779B9u;
+      b += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+  }
+};
+
+__device__ __forceinline__ float u01(uint32_t r) { return ((r >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+
+// Gamma(shape a, scale 1): Marsaglia-Tsang with the a < 1 boost; bounded rejection loop.
+__device__ float sample_gamma(float a, const Philox& ph, uint32_t gene, uint32_t row, uint32_t& draw) {
+  float boost = 1.0f;
+  if (a < 1.0f) {
+    const uint4 r = ph(gene, row, draw++, 1u);
+    boost = __powf(u01(r.x), 1.0f / a);
+    a += 1.0f;
+  }
+  const float d = a - 1.0f / 3.0f, c = rsqrtf(9.0f * d);
+  float out = d;
+  for (int it = 0; it < 16; ++it) {
+    const uint4 r = ph(gene, row, draw++, 2u);
+    const float rad = sqrtf(-2.0f * __logf(u01(r.x)));
+    const float x = rad * __cosf(6.283185307179586f * u01(r.y));
+    const float t = 1.0f + c * x;
+    if (t <= 0.f) continue;
+    const float v = t * t * t;
+    const float u = u01(r.z);
+    if (__logf(u) < 0.5f * x * x + d - d * v + d * __logf(v)) {
+      out = d * v;
+      break;
+    }
+  }
+  return out * boost;
+}
+
+// Poisson(lam): multiplication method below 10, Hoermann's PTRS above (as torch.poisson does).
+__device__ float sample_poisson(float lam, const Philox& ph, uint32_t gene, uint32_t row, uint32_t& draw) {
+  if (!(lam > 0.f)) return 0.f;
+  if (lam < 10.f) {
+    const float L = __expf(-lam);
+    float p = 1.0f;
+    int k = 0;
+    for (int it = 0; it < 32; ++it) {  // 4 uniforms per Philox call; P(k > 127 | lam < 10) ~ 0
+      const uint4 r = ph(gene, row, draw++, 3u);
+      p *= u01(r.x); if (p <= L) return (float)k; ++k;
+      p *= u01(r.y); if (p <= L) return (float)k; ++k;
+      p *= u01(r.z); if (p <= L) return (float)k; ++k;
+      p *= u01(r.w); if (p <= L) return (float)k; ++k;
+    }
+    return (float)k;
+  }
+  const float slam = sqrtf(lam), loglam = __logf(lam);
+  const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
+  const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.0f);
+  for (int it = 0; it < 32; ++it) {
+    const uint4 r = ph(gene, row, draw++, 4u);
+    const float U = u01(r.x) - 0.5f, V = u01(r.y);
+    const float us = 0.5f - fabsf(U);
+    const float k = floorf((2.0f * a / us + b) * U + lam + 0.43f);
+    if (us >= 0.07f && V <= vr) return k;
+    if (k < 0.f || (us < 0.013f && V > us)) continue;
+    if (__logf(V) + __logf(invalpha) - __logf(a / (us * us) + b) <= -lam + k * loglam - lgammaf(k + 1.0f)) return k;
+  }
+  return floorf(lam);
+}
+
+enum { SAMPLER_NB = 0, SAMPLER_MEAN = 1 };
+enum { METHOD_MEAN = 0, METHOD_PERTURBSEQ = 1 };
+
+// logits rows r = p * C + t (particle-major, the (P, n, G) layout model.forward flattens).
+template <int VPT>
+__global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* __restrict__ logits, int64_t ld,
+                                                                   const float* __restrict__ lib, int lib_n,
+                                                                   const float* __restrict__ gene_consts, float* __restrict__ sums,
+                                                                   float* __restrict__ samples, int P, int C, int G, int method,
+                                                                   int sampler, uint32_t seed_lo, uint32_t seed_hi,
+                                                                   uint32_t row_offset) {
+  __shared__ float2 red[6][4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int G4 = G >> 2;
+  const Philox ph{seed_lo, seed_hi};
+  const float libt = lib[lib_n == 1 ? 0 : t];
+  float4 c[VPT], acc[VPT];
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int k = j * 256 + tid;
+    c[j] = k < G4 ? reinterpret_cast<const float4*>(gene_consts)[k] : make_float4(1.f, 1.f, 1.f, 1.f);
+    acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int p = 0; p < P; ++p) {
+    const int64_t r = (int64_t)p * C + t;
+    const float4* L4 = reinterpret_cast<const float4*>(logits + r * ld);
+    float2* slot = red[(p & 1) * 3];
+    float4 v[VPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int k = j * 256 + tid;
+      v[j] = k < G4 ? L4[k] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      mx = fmaxf(fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)), mx);
+    }
+    mx = block_max<256>(mx, reinterpret_cast<float*>(slot));
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      v[j].x = fast_exp(v[j].x - mx); v[j].y = fast_exp(v[j].y - mx);
+      v[j].z = fast_exp(v[j].z - mx); v[j].w = fast_exp(v[j].w - mx);
+      se += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    se = block_sum<256>(se, reinterpret_cast<float*>(slot + 1));
+    const float mu_scale = libt / se;
+    float xs = 0.f;
+    const uint32_t row = row_offset + (uint32_t)r;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int k = j * 256 + tid;
+      if (k < G4) {
+        float* e = reinterpret_cast<float*>(&v[j]);
+        const float* cc = reinterpret_cast<const float*>(&c[j]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float rate = fmaxf(cc[q] / (e[q] * mu_scale + kMuEps), kRateMin);
+          float x;
+          if (sampler == SAMPLER_MEAN) {
+            x = cc[q] / rate;
+          } else {
+            uint32_t draw = 0;
+            const uint32_t gene = (uint32_t)(k * 4 + q);
+            const float lam = sample_gamma(cc[q], ph, gene, row, draw) / rate;
+            x = sample_poisson(lam, ph, gene, row, draw);
+          }
+          e[q] = x;
+          xs += x;
+        }
+        if (samples) reinterpret_cast<float4*>(samples + r * (int64_t)G)[k] = v[j];
+      }
+    }
+    if (method == METHOD_PERTURBSEQ) {
+      xs = block_sum<256>(xs, reinterpret_cast<float*>(slot + 2));
+      const float sc = 1e4f / xs;  // 0/0 -> NaN like the reference (:174)
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        acc[j].x += __log2f(v[j].x * sc + 1.0f); acc[j].y += __log2f(v[j].y * sc + 1.0f);
+        acc[j].z += __log2f(v[j].z * sc + 1.0f); acc[j].w += __log2f(v[j].w * sc + 1.0f);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        acc[j].x += v[j].x; acc[j].y += v[j].y; acc[j].z += v[j].z; acc[j].w += v[j].w;
+      }
+    }
+  }
+  float4* S4 = reinterpret_cast<float4*>(sums + (int64_t)t * G);
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int k = j * 256 + tid;
+    if (k < G4) {
+      float4 s = S4[k];
+      s.x += acc[j].x; s.y += acc[j].y; s.z += acc[j].z; s.w += acc[j].w;
+      S4[k] = s;
+    }
+  }
+}
+
+}  // namespace cradle
+
+using namespace cradle;
+
+extern "C" {
+
+// sums (C, G) += sum over the P particles of transform(x[p, t, :]), x ~ GammaPoisson(c, rate(logits)).
+// samples: optional (P*C, G) output of the raw draws (predictor.sample_observations), or NULL.
+// lib: (1) or (C) library sizes.  method: 0 raw counts, 1 "perturbseq".  sampler: 0 NB draw, 1 its mean.
+int cradle_nb_sample_accumulate(const float* logits, int64_t ld_logits, const float* library, int library_n,
+                                const float* gene_consts, float* sums, float* samples, int P, int C, int G, int method,
+                                int sampler, uint64_t seed, uint32_t row_offset, hipStream_t stream) {
+  CRADLE_CHECK_ARG(logits && library && gene_consts && sums && P > 0 && C > 0 && G > 0, "nb_sample: bad arguments");
+  CRADLE_CHECK_ARG(G % 4 == 0 && ld_logits % 4 == 0 && ld_logits >= G, "nb_sample: G and ld must be multiples of 4");
+  CRADLE_CHECK_ARG((uintptr_t)logits % 16 == 0 && (uintptr_t)sums % 16 == 0 && (uintptr_t)gene_consts % 16 == 0 &&
+                       (uintptr_t)samples % 16 == 0,
+                   "nb_sample: pointers must be 16-byte aligned");
+  CRADLE_CHECK_ARG(library_n == 1 || library_n == C, "nb_sample: library has %d entries, expected 1 or %d", library_n, C);
+  CRADLE_CHECK_ARG(method >= 0 && method <= 1 && sampler >= 0 && sampler <= 1, "nb_sample: bad method/sampler");
+  const int G4 = G / 4;
+  const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+#define CRADLE_SAMPLE_LAUNCH(VPT)                                                                              \
+  hipLaunchKernelGGL((nb_sample_accumulate_kernel<VPT>), dim3(C), dim3(256), 0, stream, logits, ld_logits, library, \
+                     library_n, gene_consts, sums, samples, P, C, G, method, sampler, lo, hi, row_offset)
+  if (G4 <= 256) CRADLE_SAMPLE_LAUNCH(1);
+  else if (G4 <= 512) CRADLE_SAMPLE_LAUNCH(2);
+  else if (G4 <= 1024) CRADLE_SAMPLE_LAUNCH(4);
+  else if (G4 <= 1536) CRADLE_SAMPLE_LAUNCH(6);
+  else if (G4 <= 2048) CRADLE_SAMPLE_LAUNCH(8);
+  else if (G4 <= 4096) CRADLE_SAMPLE_LAUNCH(16);
+  else {
+    cradle_set_error("nb_sample: n_genes=%d exceeds the supported maximum 16384", G);
+    return CRADLE_ERR_UNSUPPORTED;
+  }
+#undef CRADLE_SAMPLE_LAUNCH
+  CRADLE_CHECK_LAUNCH("nb_sample_accumulate_kernel");
+  return CRADLE_OK;
+}
+
+}  // extern "C"

@@ -99,8 +99,17 @@ class LibraryGammaPoisson:
         log_beta = torch.lgamma(c) + torch.lgamma(value + 1) - torch.lgamma(post + 1)
         return -log_beta - post.log() + c * rate.log() - post * (1 + rate).log()
 
-    def sample(self, sample_shape=torch.Size()) -> torch.Tensor:
+    def sample(self, sample_shape=torch.Size(), seed: int = None) -> torch.Tensor:
+        """x ~ GammaPoisson, drawn by the HIP sampler kernel (K9).  The Philox key comes from
+        ``seed`` or, like pyro's sampler, from torch's global generator state."""
+        from . import ops
+
+        if len(tuple(sample_shape)) != 0:
+            raise NotImplementedError("LibraryGammaPoisson.sample: only sample_shape=() (all reference call sites)")
+        if seed is None:
+            seed = int(torch.randint(0, 2**62, (1,)).item())
         with torch.no_grad():
-            c = self.concentration.expand(self._batch_shape)
-            lam = torch.distributions.Gamma(c, self.rate, validate_args=False).sample(sample_shape)
-            return torch.poisson(lam)
+            consts = ops.nb_gene_consts(self.log_concentration.detach())
+            _, x = ops.nb_sample_accumulate(
+                self.logits.detach(), self.library_size.contiguous(), consts, self.P, self.n, seed=seed, return_samples=True)
+        return x.reshape(self._batch_shape)

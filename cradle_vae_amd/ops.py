@@ -90,6 +90,36 @@ def nb_logprob_fwd_bwd(
     return out, dlogits, dlog_c
 
 
+METHODS = {"mean": 0, "perturbseq": 1}
+SAMPLERS = {"nb": 0, "mean": 1}
+
+
+def nb_sample_accumulate(
+    logits: torch.Tensor, lib: torch.Tensor, gene_consts: torch.Tensor, P: int, C: int, *, sums: Optional[torch.Tensor] = None,
+    method: str = "mean", sampler: str = "nb", seed: int = 0, row_offset: int = 0, return_samples: bool = False,
+) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """K9: draws x ~ GammaPoisson for every (particle, condition) row of ``logits`` (P*C, G)
+    and adds the (optionally perturbseq-normalised) draws of each condition, summed over its
+    particles, to ``sums`` (C, G).  -> (sums, samples or None)."""
+    G = logits.shape[1]
+    if logits.shape[0] != P * C or lib.numel() not in (1, C) or gene_consts.shape[-1] != G:
+        raise hip.CradleHipError(
+            f"nb_sample: shape mismatch logits {tuple(logits.shape)} lib {tuple(lib.shape)} for P={P} C={C}")
+    if sums is None:
+        sums = torch.zeros((C, G), device=logits.device, dtype=torch.float32)
+    if sums.shape != (C, G):
+        raise hip.CradleHipError(f"nb_sample: sums has shape {tuple(sums.shape)}, expected {(C, G)}")
+    samples = torch.empty((P * C, G), device=logits.device, dtype=torch.float32) if return_samples else None
+    hip.check(
+        hip.load().cradle_nb_sample_accumulate(
+            hip.ptr(logits), logits.stride(0), hip.ptr(lib), lib.numel(), hip.ptr(gene_consts), hip.ptr(sums),
+            hip.ptr(samples), P, C, G, METHODS[method], SAMPLERS[sampler], seed & (2**64 - 1), row_offset & 0xFFFFFFFF,
+            hip.stream()),
+        "nb_sample_accumulate",
+    )
+    return sums, samples
+
+
 NT, NN, TN = 0, 1, 2
 
 

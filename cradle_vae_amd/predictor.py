@@ -1,0 +1,244 @@
+"""Predictor -- mirror of the reference's ``PerturbationPlatedPredictor``
+(cradle_vae/models/utils/predictor.py:24-410) and ``cradle_vae_Predictor``
+(cradle_vae/models/cradle_vae/predictor.py:6-13) on the HIP kernels.
+
+Results come back in ``anndata.AnnData`` when anndata is importable, otherwise in
+``AnnDataLite`` (same ``X`` / ``obs`` / ``var`` / ``uns`` attributes).
+``estimate_qc_ratio`` (predictor.py:412-438) needs rapids_singlecell/cupy/scanpy, which
+are CUDA-only third-party tools outside this path; it raises ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, Literal, Optional, Sequence, Union
+
+import numpy as np
+import pandas as pd
+import torch
+from torch import nn
+
+from . import ops
+from .ate import estimate_model_average_treatment_effect
+
+try:  # pragma: no cover - anndata is absent from the build image
+    from anndata import AnnData as _AnnData
+except Exception:  # noqa: BLE001
+    _AnnData = None
+
+
+class AnnDataLite:
+    """The slice of the AnnData surface the reference's callers of the predictor touch
+    (eval.py:88-133): ``X``, ``obs``, ``var``, ``uns``, ``shape``, ``obs_names``/``var_names``."""
+
+    def __init__(self, X=None, obs: Optional[pd.DataFrame] = None, var: Optional[pd.DataFrame] = None, uns=None):
+        self.X = np.asarray(X)
+        self.obs = obs if obs is not None else pd.DataFrame(index=pd.RangeIndex(self.X.shape[0]).astype(str))
+        self.var = var if var is not None else pd.DataFrame(index=pd.RangeIndex(self.X.shape[1]).astype(str))
+        self.uns = dict(uns) if uns is not None else {}
+
+    @property
+    def shape(self):
+        return self.X.shape
+
+    @property
+    def obs_names(self):
+        return self.obs.index
+
+    @property
+    def var_names(self):
+        return self.var.index
+
+
+def make_anndata(X, obs=None, var=None, uns=None):
+    if _AnnData is not None:  # pragma: no cover
+        kw = {k: v for k, v in dict(obs=obs, var=var, uns=uns).items() if v is not None}
+        return _AnnData(X=X, **kw)
+    return AnnDataLite(X=X, obs=obs, var=var, uns=uns)
+
+
+class PerturbationPlatedPredictor(nn.Module):
+    def __init__(
+        self,
+        model: nn.Module,
+        guide: nn.Module,
+        local_variables: Optional[Iterable[str]] = None,
+        perturbation_plated_variables: Optional[Iterable[str]] = None,
+        dosage_independent_variables: Optional[Iterable[str]] = None,
+    ):
+        super().__init__()
+        local_variables = list(local_variables) if local_variables is not None else []
+        perturbation_plated_variables = (
+            list(perturbation_plated_variables) if perturbation_plated_variables is not None else [])
+        # predictor.py:44-57
+        assert sorted(model.get_var_keys()) == sorted(guide.get_var_keys()), "Mismatch in model and guide variables"
+        variables = local_variables + perturbation_plated_variables
+        assert sorted(list(model.get_var_keys())) == sorted(variables), (
+            "Mismatch between model variables and variables specified to loss module")
+        if dosage_independent_variables is not None:
+            assert set(dosage_independent_variables).issubset(set(variables))
+        self.model = model.eval()
+        self.guide = guide.eval()
+        self.local_variables = local_variables
+        self.perturbation_plated_variables = perturbation_plated_variables
+        self.dosage_independent_variables = dosage_independent_variables
+
+    def _get_device(self):
+        return next(self.model.parameters()).device
+
+    # ------------------------------------------------------------------ IWELBO
+    @torch.no_grad()
+    def iwelbo_batch(self, batch: Dict[str, torch.Tensor], plated: Dict[str, torch.Tensor], n_particles: int,
+                     noise: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+        """One batch of predictor.py:125-185 -> (n,) log-mean-exp over particles of
+        log p(x|z,...) + log p(z) - log q(z|x,...), the plated variables held at ``plated``."""
+        X, D, qc = batch["X"], batch["D"], batch["qc"]
+        guide_dists, guide_samples = self.guide(
+            X=X, D=D, qc=qc, condition_values=plated, n_particles=n_particles, noise=noise)
+        guide_samples = dict(guide_samples)
+        guide_samples["library_size"] = batch["library_size"]
+        model_dists, _ = self.model(D=D, qc=qc, condition_values=guide_samples, n_particles=n_particles, sample_x=False)
+        lp_good = model_dists["p_x_good"].log_prob_sum(X)  # (P, n): K1 forward
+        lp_bad = model_dists["p_x_bad"].log_prob_sum(X)
+        b_qc = qc.max(dim=1)[0] if qc.shape[1] > 1 else qc[:, 0]  # :160-164
+        terms = (1 - b_qc) * lp_good + b_qc * lp_bad
+        for var_name in self.local_variables:  # :166-177
+            v = guide_samples[var_name]
+            terms = terms + model_dists[f"p_{var_name}"].log_prob(v).sum(-1) - guide_dists[f"q_{var_name}"].log_prob(v).sum(-1)
+        return torch.logsumexp(terms, dim=0) - math.log(n_particles)  # :183-185
+
+    @torch.no_grad()
+    def compute_predictive_iwelbo(self, loaders, n_particles: int,
+                                  noise: Optional[Dict[str, torch.Tensor]] = None) -> pd.DataFrame:
+        """predictor.py:77-200.  ``noise`` (u_mask, eps_E, eps_qc_E (P,...) and eps_z (P, n_total, L)
+        in loader order) injects the draws for parity tests."""
+        if not isinstance(loaders, (list, tuple)):
+            loaders = [loaders]
+        device = self._get_device()
+        _, guide_samples = self.guide(n_particles=n_particles, noise=noise)  # :104
+        plated = {k: guide_samples[k] for k in self.perturbation_plated_variables}
+        id_list, iwelbo_list = [], []
+        seen = 0
+        for loader in loaders:
+            idx_list_curr = []
+            for batch in loader:
+                batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                idx_list_curr.append(batch["idx"].detach().cpu().numpy())
+                n = batch["X"].shape[0]
+                nz = None
+                if noise is not None and "eps_z" in noise:
+                    nz = {"eps_z": noise["eps_z"][:, seen:seen + n].to(device).contiguous()}
+                seen += n
+                iwelbo_list.append(self.iwelbo_batch(batch, plated, n_particles, nz).cpu().numpy())
+            idx_curr = np.concatenate(idx_list_curr)
+            id_list.append(loader.dataset.convert_idx_to_ids(idx_curr))
+        return pd.DataFrame(index=np.concatenate(id_list), columns=["IWELBO"],
+                            data=np.concatenate(iwelbo_list).reshape(-1, 1))
+
+    # ------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def sample_observations(
+        self,
+        dosages: torch.Tensor,
+        perturbation_names: Optional[Sequence[str]],
+        n_particles: int = 1,
+        condition_values: Optional[Dict[str, torch.Tensor]] = None,
+        x_var_info: Optional[pd.DataFrame] = None,
+        qc=None,
+    ):
+        """predictor.py:202-273 -> (adata_good, adata_bad); rows ordered perturbation-major
+        (all particles of dosage 0, then dosage 1, ...) like the reference's concatenation.
+
+        All dosages are decoded in one pass and drawn by one sampler launch per variant instead
+        of the reference's per-dosage loop (:239-245)."""
+        device = self._get_device()
+        dosages = dosages.to(device=device, dtype=torch.float32)
+        qc = qc.to(device=device, dtype=torch.float32)
+        _, guide_samples = self.guide(n_particles=n_particles)
+        cv = {} if condition_values is None else {k: v.to(device) for k, v in condition_values.items()}
+        for var_name in self.perturbation_plated_variables:
+            cv[var_name] = guide_samples[var_name]
+        n = dosages.shape[0]
+        qc_rows = qc.expand(n, -1) if qc.shape[0] == 1 else qc
+        dists, _ = self.model(D=dosages, qc=qc_rows, condition_values=cv, n_particles=n_particles, sample_x=False)
+        out = []
+        for key in ("p_x_good", "p_x_bad"):
+            x = dists[key].sample()  # (P, n, G)
+            out.append(x.permute(1, 0, 2).reshape(n * n_particles, -1).cpu().numpy())
+        adatas = []
+        for x in out:
+            obs = pd.DataFrame(index=np.arange(x.shape[0]))
+            obs["perturbation_idx"] = np.repeat(np.arange(n), n_particles)
+            # the reference writes np.tile(np.arange(n_dosages), n_particles) here (:251), which
+            # labels rows with a dosage counter; the particle index is what the column name says
+            obs["particle_idx"] = np.tile(np.arange(n_particles), n)
+            if perturbation_names is not None:
+                obs["perturbation_name"] = np.array(perturbation_names)[obs["perturbation_idx"].to_numpy()]
+            adatas.append(make_anndata(x, obs=obs, var=x_var_info.copy() if x_var_info is not None else None))
+        return adatas[0], adatas[1]
+
+    def sample_observations_data_module(self, data_module, n_particles: int,
+                                        condition_values: Optional[Dict[str, torch.Tensor]] = None, qc=None):
+        """predictor.py:275-310."""
+        perturbation_names = data_module.get_unique_observed_intervention_info().index
+        D = data_module.get_unique_observed_intervention_dosages(perturbation_names)
+        return self.sample_observations(
+            dosages=D, perturbation_names=perturbation_names, x_var_info=data_module.get_x_var_info(),
+            n_particles=n_particles, condition_values=condition_values, qc=qc)
+
+    # ------------------------------------------------------------------ ATE
+    @torch.no_grad()
+    def estimate_average_treatment_effects(
+        self,
+        dosages_alt: torch.Tensor,
+        dosages_control: torch.Tensor,
+        quality: torch.Tensor,
+        method: Literal["mean", "perturbseq"],
+        n_particles: int = 1000,
+        condition_values: Optional[Dict[str, torch.Tensor]] = None,
+        perturbation_names_alt: Optional[Sequence[str]] = None,
+        perturbation_name_control: Optional[str] = None,
+        x_var_info: Optional[pd.DataFrame] = None,
+        batch_size: int = 500,
+        **estimator_kwargs,
+    ):
+        """predictor.py:312-371."""
+        device = self._get_device()
+        cv = None if condition_values is None else {k: v.to(device) for k, v in condition_values.items()}
+        ate = estimate_model_average_treatment_effect(
+            model=self.model, guide=self.guide, dosages_alt=dosages_alt.to(device),
+            dosages_control=dosages_control.to(device), quality=quality.to(device), n_particles=n_particles,
+            method=method, condition_values=cv, batch_size=batch_size,
+            dosage_independent_variables=self.dosage_independent_variables, **estimator_kwargs)
+        obs = pd.DataFrame(index=np.array(perturbation_names_alt)) if perturbation_names_alt is not None else None
+        uns = {"control": perturbation_name_control} if perturbation_name_control is not None else None
+        return make_anndata(ate, obs=obs, var=x_var_info.copy() if x_var_info is not None else None, uns=uns)
+
+    def estimate_average_effects_data_module(
+        self, data_module, control_label: str, method: Literal["mean", "perturbseq"], n_particles: int = 100,
+        condition_values: Optional[Dict[str, torch.Tensor]] = None, batch_size: int = 500, **estimator_kwargs,
+    ):
+        """predictor.py:373-410."""
+        perturbation_names = data_module.get_unique_observed_intervention_info().index
+        perturbation_names_alt = [name for name in perturbation_names if name != control_label]
+        dosages_alt = data_module.get_unique_observed_intervention_dosages(perturbation_names_alt)
+        dosages_ref = data_module.get_unique_observed_intervention_dosages([control_label])
+        good_quality = torch.ones((1, data_module.get_qc_var_info().shape[0]))  # :394
+        return self.estimate_average_treatment_effects(
+            dosages_alt=dosages_alt, dosages_control=dosages_ref, quality=good_quality, method=method,
+            n_particles=n_particles, condition_values=condition_values, perturbation_names_alt=perturbation_names_alt,
+            perturbation_name_control=control_label, x_var_info=data_module.get_x_var_info(), batch_size=batch_size,
+            **estimator_kwargs)
+
+    def estimate_qc_ratio(self, *args, **kwargs):
+        raise NotImplementedError(
+            "estimate_qc_ratio (predictor.py:412-438) post-processes samples with rapids_singlecell / cupy "
+            "(CUDA-only third-party tools); it is outside the MI355X hot path. Use sample_observations_data_module "
+            "and annotate the counts with a CPU QC tool.")
+
+
+class cradle_vae_Predictor(PerturbationPlatedPredictor):
+    """cradle_vae/models/cradle_vae/predictor.py:6-13."""
+
+    def __init__(self, model: nn.Module, guide: nn.Module):
+        super().__init__(model=model, guide=guide, local_variables=["z_basal"],
+                         perturbation_plated_variables=["E", "mask", "qc_E"])

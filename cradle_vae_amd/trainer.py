@@ -11,6 +11,8 @@ from typing import Dict, Optional
 
 import torch
 
+from . import parallel
+
 
 class TrainStep:
     def __init__(self, loss_module, lr: float, weight_decay: float = 1e-6,
@@ -23,9 +25,8 @@ class TrainStep:
         self.device = self.params[0].device
         # plated draws (mask, E, qc_E) must agree across ranks, local draws (z_basal) must not:
         # two generators, the first seeded identically everywhere
-        self.gen_plated = torch.Generator(device=self.device).manual_seed(seed)
         rank = torch.distributed.get_rank() if world_size > 1 else 0
-        self.gen_local = torch.Generator(device=self.device).manual_seed(seed + 7919 * (rank + 1))
+        self.gen_plated, self.gen_local = parallel.make_generators(seed, rank, self.device)
         self.impl = "modular"
         self.decoder_variants = 2
         self.lr, self.weight_decay = lr, weight_decay
@@ -44,32 +45,11 @@ class TrainStep:
 
     def draw_noise(self, P, N):
         g = self.lm.guide
-        T, L, Q = g.n_treatments, g.n_latent, g.n_qc
-        d = self.device
-
-        def one():
-            return dict(
-                u_mask=torch.rand((P, T, L), device=d, generator=self.gen_plated),
-                eps_E=torch.randn((P, T, L), device=d, generator=self.gen_plated),
-                eps_qc_E=torch.randn((P, Q, L), device=d, generator=self.gen_plated),
-                eps_z=torch.randn((P, N, L), device=d, generator=self.gen_local),
-            )
-
-        return one(), one()
+        args = (self.gen_plated, self.gen_local, P, N, g.n_treatments, g.n_latent, g.n_qc, self.device)
+        return parallel.draw_noise(*args), parallel.draw_noise(*args)
 
     def allreduce_grads(self):
-        if self.world_size == 1:
-            return
-        import torch.distributed as dist
-
-        flat = torch.cat([p.grad.reshape(-1) for p in self.params])
-        dist.all_reduce(flat)
-        flat.div_(self.world_size)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p))
-            off += n
+        parallel.allreduce_mean_grads_(self.params, self.world_size)
 
     def _fused_call(self, batch, n_particles):
         from . import hip, ops
@@ -81,10 +61,7 @@ class TrainStep:
                 qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
                 n_particles=n_particles, gen_plated=self.gen_plated, gen_local=self.gen_local)
         a = f.arena
-        if self.world_size > 1:
-            import torch.distributed as dist
-
-            dist.all_reduce(a.grad)  # one RCCL call on the flat gradient arena; averaged inside Adam
+        parallel.allreduce_sum_(a.grad, self.world_size)  # one RCCL call on the flat gradient arena; averaged inside Adam
         self.step_count += 1
         hip.check(
             hip.load().cradle_adam_step(

@@ -187,6 +187,19 @@ int cradle_adam_step(float* params, const float* grads, float* exp_avg, float* e
                      float grad_scale, float* norm_ws, cradle_stream_t stream);
 int64_t cradle_adam_workspace_floats(void);
 
+/* ---- K9: Gamma-Poisson observation sampler fused with the ATE accumulation ---------------
+ * Replaces, per (particle p, condition t) row r = p*C + t of decoder logits:
+ *   mlp.py:153-166 (softmax -> mu -> rate) + pyro GammaPoisson.sample at model.py:131
+ *   (rate' ~ Gamma(c, rate), x ~ Poisson(rate')) + average_treatment_effects.py:171-176,190-195
+ *   (method "perturbseq": log2(1e4*x/sum_g x + 1); X_sums[t] += sum over particles).
+ * sums (C, G) is accumulated into (+=).  samples: NULL or (P*C, G) raw draws
+ * (predictor.py:228-251 sample_observations).  library: 1 or C entries.  method: 0 raw counts,
+ * 1 perturbseq.  sampler: 0 Gamma-Poisson draw (Philox4x32-10 keyed by seed, counter = gene,
+ * row_offset + r, draw index), 1 the distribution mean c/rate (deterministic, for parity tests). */
+int cradle_nb_sample_accumulate(const float* logits, int64_t ld_logits, const float* library, int library_n,
+                                const float* gene_consts, float* sums, float* samples, int P, int C, int G,
+                                int method, int sampler, uint64_t seed, uint32_t row_offset, cradle_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
