@@ -54,6 +54,34 @@ def build(shape, device, seed):
     return lm, batch
 
 
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (256 CUs x 256 flop/clk x 2.4 GHz)
+
+
+def k1_pmc_traffic(G, N, P):
+    """HBM bytes per K1 launch from the committed rocprofv3 --pmc passes (profiles/k1_pmc.json:
+    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate runs of tools/pmc_nb.py); None if no pass was
+    made at this shape."""
+    path = os.path.join(ROOT, "profiles", "k1_pmc.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except OSError:
+        return None
+    if d.get("shape") != {"G": G, "N": N, "P": P}:
+        return None
+    return d.get("traffic_bytes")
+
+
+def gemm_flops_fwd(s):
+    """Forward MLP GEMM flops of one step in the minimal form of SURVEY 8(d) (2 flops per MAC)."""
+    N, P, G, T, L = s.n_cells, s.n_particles, s.n_phenos, s.n_treatments, s.n_latent
+    He, Hd, Hm = s.basal_encoder_n_hidden, s.decoder_n_hidden, s.embedding_encoder_n_hidden
+    f_enc = 2 * 2 * N * G * He + 3 * 2 * P * N * (2 * L * He + 2 * He * L)
+    f_dec = 2 * P * N * (3 * L * Hd + Hd * Hd * max(s.decoder_n_layers, 1) + Hd * G)
+    f_emb = 2 * 2 * P * T * (L * Hm + (s.embedding_encoder_n_layers - 1) * Hm * Hm + 2 * Hm * L)
+    return float(f_enc + f_dec + f_emb)
+
+
 def cpu_baseline(shape, seconds_budget=25.0):
     """The reference's PyTorch path (CPU oracle restatement, fp32, autograd + Adam), timed on
     this host's cores on a bounded sample of the same workload."""
@@ -171,8 +199,9 @@ def main():
     if rank == 0:
         # ---- roofline of K1 from the HIP events recorded around its launches in the timed region
         P, N, G = shape.n_particles, shape.n_cells, shape.n_phenos
-        k1 = [s.elapsed_time(e) * 1e-3 for (name, s, e) in ops.KERNEL_TIMERS if name == "nb_logprob_fwd_bwd"]
-        if stepper.fused is not None:  # events recorded by the C step around its K1 launches
+        # (HIP events recorded by the C code immediately around nb_rows_kernel, on its launch stream)
+        k1 = [t[1].elapsed_ms() * 1e-3 for t in ops.KERNEL_TIMERS if t[0] == "nb_logprob_fwd_bwd"]
+        if stepper.fused is not None:
             k1 = [ev.elapsed_ms() * 1e-3 for ev in stepper.fused.k1_events]
         V = stepper.decoder_variants  # decoder variants scored per cell (2 = as the reference, 1 = live variant only)
         alg_bytes = 4.0 * G * (3 * P * N + 2 * N)  # SURVEY 8(d) per launch of one variant: fwd+bwd
@@ -182,10 +211,18 @@ def main():
             ach = alg_bytes / t_k1 / 1e9
             roofline = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "nb_rows_kernel<BWD> (K1 fused fwd+bwd, one decoder variant per launch)",
+                "traffic": k1_pmc_traffic(G, N, P),
+                "kernel": "nb_rows_kernel<BWD> (K1 fused fwd+bwd, one decoder variant per launch)",
                 "launch_us": t_k1 * 1e6, "launches_per_step": len(k1) / args.steps,
                 "algorithmic_bytes_per_launch": alg_bytes,
             }
+        # MFMA side: minimal-form GEMM flops of the step (fwd+bwd = 3x fwd) over the whole
+        # step time, against the dense fp32 matrix-core peak -- a lower bound on MFMA utilisation
+        # while the GEMMs run, since the step time also holds every non-GEMM kernel.
+        gf = gemm_flops_fwd(shape) * 3
+        mfma = {"flops_per_step": gf, "achieved": gf / (elapsed / args.steps) / 1e12, "peak": MFMA_F32_PEAK_TF,
+                "unit": "TFLOP/s", "frac": gf / (elapsed / args.steps) / 1e12 / MFMA_F32_PEAK_TF,
+                "note": "minimal-form MLP GEMM flops (SURVEY 8d) / whole step time; fp32 v_mfma_f32_32x32x2_f32"}
         out = {
             "metric": "cells/sec ELBO fwd+bwd (Norman shape)",
             "value": cells_per_s,
@@ -206,6 +243,7 @@ def main():
                 "loss": float(loss),
             },
             "roofline": roofline,
+            "mfma": mfma,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(shape)

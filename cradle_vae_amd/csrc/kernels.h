@@ -49,6 +49,11 @@ int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlo
                               const float* X, int64_t ldx, const float* lib, const float* gene_consts,
                               const float* grow, float* out, float* dlog_c, int accumulate_dlog_c, float* workspace,
                               int64_t workspace_floats, int P, int N, int G, hipStream_t stream);
+int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
+                                    const float* X, int64_t ldx, const float* lib, const float* gene_consts,
+                                    const float* grow, float* out, float* dlog_c, int accumulate_dlog_c,
+                                    float* workspace, int64_t workspace_floats, int P, int N, int G, void* ev_begin,
+                                    void* ev_end, hipStream_t stream);
 }
 namespace cradle {
 

@@ -303,11 +303,13 @@ int cradle_nb_logprob_fwd(const float* logits, int64_t ld_logits, const float* X
                                N, G, PS, stream);
 }
 
-int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
-                              const float* X, int64_t ldx, const float* lib, const float* gene_consts,
-                              const float* grow, float* out, float* dlog_c, int accumulate_dlog_c,
-                              float* workspace, int64_t workspace_floats, int P, int N, int G,
-                              hipStream_t stream) {
+// Optional events (cradle_event_create handles) are recorded on `stream` immediately around the
+// rows kernel (the dominant launch; the small column sum that follows is outside the bracket).
+int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
+                                    const float* X, int64_t ldx, const float* lib, const float* gene_consts,
+                                    const float* grow, float* out, float* dlog_c, int accumulate_dlog_c,
+                                    float* workspace, int64_t workspace_floats, int P, int N, int G, void* ev_begin,
+                                    void* ev_end, hipStream_t stream) {
   int rc = check_common(logits, X, lib, gene_consts, out, P, N, G, ld_logits, ldx);
   if (rc) return rc;
   CRADLE_CHECK_ARG(dlogits && grow && dlog_c && workspace, "nb_logprob_fwd_bwd: null pointer argument");
@@ -317,13 +319,25 @@ int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlo
   CRADLE_CHECK_ARG(workspace_floats >= (int64_t)N * PS * G && (uintptr_t)workspace % 16 == 0,
                    "nb_logprob_fwd_bwd: workspace needs %lld floats, 16-byte aligned (got %lld)",
                    (long long)((int64_t)N * PS * G), (long long)workspace_floats);
+  if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, stream);
   rc = launch_nb_rows<true>(logits, ld_logits, dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, workspace,
                             P, N, G, PS, stream);
+  if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(colsum_kernel, dim3((G + 63) / 64), dim3(1024), 0, stream, workspace, N * PS, G, dlog_c,
                      accumulate_dlog_c);
   CRADLE_CHECK_LAUNCH("colsum_kernel");
   return CRADLE_OK;
+}
+
+int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
+                              const float* X, int64_t ldx, const float* lib, const float* gene_consts,
+                              const float* grow, float* out, float* dlog_c, int accumulate_dlog_c,
+                              float* workspace, int64_t workspace_floats, int P, int N, int G,
+                              hipStream_t stream) {
+  return cradle_nb_logprob_fwd_bwd_timed(logits, ld_logits, dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out,
+                                         dlog_c, accumulate_dlog_c, workspace, workspace_floats, P, N, G, nullptr,
+                                         nullptr, stream);
 }
 
 int64_t cradle_nb_workspace_floats(int P, int N, int G) {

@@ -14,7 +14,7 @@ from . import hip
 # Optional HIP-event timing of individual launches (bench.py: roofline of K1).  Events are
 # recorded on the stream the kernel is launched on (torch's current stream).
 KERNEL_TIMING = False
-KERNEL_TIMERS = []  # (name, start_event, end_event)
+KERNEL_TIMERS = []  # (name, hip.EventPair) for K1; (name, start_event, end_event) for _timed regions
 
 
 class _timed:
@@ -79,14 +79,18 @@ def nb_logprob_fwd_bwd(
     need = lib_.cradle_nb_workspace_floats(P, N, G)
     if workspace is None:
         workspace = torch.empty((need,), device=X.device, dtype=torch.float32)
-    with _timed("nb_logprob_fwd_bwd"):
-        hip.check(
-            lib_.cradle_nb_logprob_fwd_bwd(
-                hip.ptr(logits), logits.stride(0), hip.ptr(dlogits), dlogits.stride(0), hip.ptr(X), X.stride(0),
-                hip.ptr(lib), hip.ptr(gene_consts), hip.ptr(grow), hip.ptr(out), hip.ptr(dlog_c), int(accumulate),
-                hip.ptr(workspace), workspace.numel(), P, N, G, hip.stream()),
-            "nb_logprob_fwd_bwd",
-        )
+    ev = None
+    if KERNEL_TIMING:  # HIP events right around the rows kernel, on the launch stream
+        ev = hip.EventPair()
+        KERNEL_TIMERS.append(("nb_logprob_fwd_bwd", ev))
+    hip.check(
+        lib_.cradle_nb_logprob_fwd_bwd_timed(
+            hip.ptr(logits), logits.stride(0), hip.ptr(dlogits), dlogits.stride(0), hip.ptr(X), X.stride(0),
+            hip.ptr(lib), hip.ptr(gene_consts), hip.ptr(grow), hip.ptr(out), hip.ptr(dlog_c), int(accumulate),
+            hip.ptr(workspace), workspace.numel(), P, N, G, ev.begin if ev else None, ev.end if ev else None,
+            hip.stream()),
+        "nb_logprob_fwd_bwd",
+    )
     return out, dlogits, dlog_c
 
 

@@ -90,3 +90,62 @@ class TrainStep:
         self.optimizer.step()
         self.last_metrics = metrics
         return loss.detach()
+
+
+def fit(module, train_loader, val_loader=None, *, max_epochs: int = 1, max_steps: Optional[int] = None,
+        gradient_clip_val: Optional[float] = 100.0, seed: int = 0, log_every: int = 0, callbacks=()):
+    """What ``pl.Trainer(...).fit(lightning_module, datamodule)`` does in train_norman.py:89-104
+    for this module, without pytorch_lightning: epochs over ``train_loader`` with ``TrainStep``
+    (fused HIP step + RCCL all-reduce + clip + Adam), then ``validation_step`` over
+    ``val_loader``.  Returns a history list of dicts (``epoch``, ``train/loss``, ``val/loss`` ...).
+
+    ``module`` is a ``PerturbationLightningModule``; loaders yield batch dicts on the module's
+    device (``cradle_vae_amd.data.DeviceBatchLoader``).  ``callbacks``: callables
+    ``cb(module, epoch, record)`` run after each epoch (checkpointing, early stopping by raising
+    StopIteration)."""
+    from . import parallel
+
+    world, _ = parallel.world_and_rank()
+    if getattr(module, "use_scheduler", False):
+        raise NotImplementedError("use_scheduler=True (SGD + CyclicLR) is never enabled by the reference's entry "
+                                  "points (train_norman.py:82); drive configure_optimizers() yourself for it")
+    stepper = TrainStep(module.loss_module, lr=module.lr, weight_decay=module.weight_decay,
+                        gradient_clip_norm=gradient_clip_val, world_size=world, seed=seed)
+    history, steps = [], 0
+    for epoch in range(max_epochs):
+        module.train()
+        if hasattr(train_loader, "set_epoch"):
+            train_loader.set_epoch(epoch)
+        tot, cnt = None, 0
+        for batch in train_loader:
+            b = dict(batch)
+            b["D_obs_counts"], b["qc_obs_counts"] = module.D_obs_counts_train, module.qc_obs_counts_train
+            loss = stepper(b, n_particles=module.n_particles)
+            tot = loss.detach().clone() if tot is None else tot + loss.detach()
+            cnt += 1
+            steps += 1
+            if log_every and steps % log_every == 0:
+                print(f"epoch {epoch} step {steps} train/loss {float(loss):.4f}", flush=True)
+            if max_steps is not None and steps >= max_steps:
+                break
+        record = {"epoch": epoch, "steps": steps, "train/loss": float(tot / max(cnt, 1)) if tot is not None else None}
+        if val_loader is not None:
+            module.eval()
+            vtot, vcnt = None, 0
+            for batch in val_loader:
+                v = module.validation_step(batch, vcnt).detach() * batch["X"].shape[0]
+                vtot = v if vtot is None else vtot + v
+                vcnt += batch["X"].shape[0]
+            if vtot is not None:
+                t = torch.stack([vtot, torch.tensor(float(vcnt), device=vtot.device)])
+                parallel.allreduce_sum_(t, world)
+                record["val/loss"] = float(t[0] / t[1])
+        history.append(record)
+        try:
+            for cb in callbacks:
+                cb(module, epoch, record)
+        except StopIteration:
+            break
+        if max_steps is not None and steps >= max_steps:
+            break
+    return history

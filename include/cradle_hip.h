@@ -73,6 +73,14 @@ int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlo
                               const float* grow, float* out, float* dlog_concentration, int accumulate,
                               float* workspace, int64_t workspace_floats, int P, int N, int G,
                               cradle_stream_t stream);
+/* Same; ev_begin / ev_end (cradle_event_create handles, or NULL) are recorded on `stream`
+ * immediately around the rows kernel, the launch bench.py's roofline describes (the small
+ * column sum that finishes dlog_concentration runs after ev_end). */
+int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
+                                    const float* X, int64_t ldx, const float* library, const float* gene_consts,
+                                    const float* grow, float* out, float* dlog_concentration, int accumulate,
+                                    float* workspace, int64_t workspace_floats, int P, int N, int G,
+                                    void* ev_begin, void* ev_end, cradle_stream_t stream);
 int64_t cradle_nb_workspace_floats(int P, int N, int G);
 int cradle_nb_particle_split(int P, int N);
 /* tuning hook for tools/bench_nb.py: threads per workgroup (256/512/1024), particle split; -1 = auto */

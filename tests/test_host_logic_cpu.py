@@ -1,0 +1,171 @@
+"""Host-side logic that needs no GPU: the config-built training module, checkpoints in
+Lightning's layout, the device batch source (on CPU tensors), namespaces, and the rule that
+the product path refuses to compute without the GPU (no CPU fallback)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_io as gio
+
+
+def _config(cfg, log_mean, log_std):
+    from cradle_vae_amd.guide import ObservationNormalizationStatistics
+
+    return dict(
+        model="cradle_vae_Model", guide="cradle_vae_CorrelatedNormalGuide", loss_module="cradle_vae_ELBOLossModule",
+        predictor="cradle_vae_Predictor", data_module="NormanOODCombinationDataModule",
+        data_module_kwargs=dict(n_qc_pass=80, n_qc_fail=20),
+        lightning_module_kwargs=dict(lr=3e-4, n_particles=cfg["n_particles"]),
+        loss_module_kwargs=dict(beta=cfg["beta"]),
+        model_kwargs=dict(
+            n_latent=cfg["n_latent"], n_treatments=cfg["n_treatments"], n_phenos=cfg["n_phenos"], n_qc=cfg["n_qc"],
+            mask_prior_prob=cfg["mask_prior_prob"], embedding_prior_scale=cfg["embedding_prior_scale"],
+            likelihood_key="library_nb", decoder_n_layers=cfg["decoder_n_layers"],
+            decoder_n_hidden=cfg["decoder_n_hidden"], sum_mode=False),
+        guide_kwargs=dict(
+            n_latent=cfg["n_latent"], n_treatments=cfg["n_treatments"], n_phenos=cfg["n_phenos"], n_qc=cfg["n_qc"],
+            basal_encoder_n_layers=cfg["basal_encoder_n_layers"], basal_encoder_n_hidden=cfg["basal_encoder_n_hidden"],
+            basal_encoder_input_normalization="log_standardize",
+            embedding_encoder_n_layers=cfg["embedding_encoder_n_layers"],
+            embedding_encoder_n_hidden=cfg["embedding_encoder_n_hidden"],
+            x_normalization_stats=ObservationNormalizationStatistics(log_x_mean=log_mean, log_x_std=log_std)),
+    )
+
+
+def _module(case, with_counts=True):
+    from cradle_vae_amd.models.utils.perturbation_lightning_module import TrainConfigPerturbationLightningModule
+
+    cfg, p, b = case["cfg"], case["params"], case["batch"]
+    config = _config(cfg, p["guide.normalization_module.log_mean"].clone(), p["guide.normalization_module.log_scale"].clone())
+    kw = {}
+    if with_counts:
+        kw = dict(D_obs_counts_train=b["D_obs_counts"], D_obs_counts_val=b["D_obs_counts"], D_obs_counts_test=b["D_obs_counts"],
+                  qc_obs_counts_train=b["qc_obs_counts"], qc_obs_counts_val=b["qc_obs_counts"],
+                  qc_obs_counts_test=b["qc_obs_counts"])
+    return TrainConfigPerturbationLightningModule(config=config, **kw)
+
+
+def test_models_namespace_matches_reference_exports():
+    import cradle_vae_amd.models as m
+
+    for name in ("cradle_vae_Model", "cradle_vae_CorrelatedNormalGuide", "cradle_vae_ELBOLossModule",
+                 "cradle_vae_CustomReweightedELBOLossModule", "cradle_vae_IWELBOLossModule", "cradle_vae_Predictor"):
+        assert hasattr(m, name), name
+    from cradle_vae_amd.analysis.average_treatment_effects import estimate_model_average_treatment_effect  # noqa: F401
+    from cradle_vae_amd.models.utils.predictor import PerturbationPlatedPredictor  # noqa: F401
+
+
+def test_config_module_state_dict_has_reference_keys():
+    case = gio.load_elbo("tiny")
+    mod = _module(case)
+    sd = mod.state_dict()
+    # the reference's checkpoint keys: loss_module.{model,guide}.* and the same tensors again under predictor.*
+    for k, v in case["params"].items():
+        assert f"loss_module.{k}" in sd and f"predictor.{k}" in sd, k
+        assert tuple(sd[f"loss_module.{k}"].shape) == tuple(v.shape), k
+    assert mod.predictor.model is mod.loss_module.model and mod.predictor.guide is mod.loss_module.guide
+    assert mod.loss_module.pos_weight == 0.8 and mod.n_particles == case["cfg"]["n_particles"]
+    assert not mod.predictor.model.training  # predictor puts both in eval mode (predictor.py:60-61)
+    missing, unexpected = mod.loss_module.load_state_dict(case["params"], strict=True)
+    assert not missing and not unexpected
+    opt = mod.configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["weight_decay"] == 1e-6
+
+
+def test_obs_count_placeholders_and_condition_values():
+    case = gio.load_elbo("tiny")
+    mod = _module(case, with_counts=False)
+    T, Q = case["cfg"]["n_treatments"], case["cfg"]["n_qc"]
+    for split in ("train", "val", "test"):
+        assert torch.equal(getattr(mod, f"D_obs_counts_{split}"), -torch.ones(T))
+        assert torch.equal(getattr(mod, f"qc_obs_counts_{split}"), -torch.ones(Q))
+    cv = mod._get_extra_condition_values(dict(X=1, D=2, qc=3, cfX=4, library_size=5, idx=6))
+    assert set(cv) == {"qc", "cfX", "library_size", "idx"}
+    with pytest.raises(NotImplementedError):
+        mod.get_data_module()
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from cradle_vae_amd.lightning_module import load_checkpoint, save_checkpoint
+
+    case = gio.load_elbo("tiny")
+    mod = _module(case)
+    mod.loss_module.load_state_dict(case["params"], strict=True)
+    path = os.path.join(tmp_path, "last.ckpt")
+    save_checkpoint(mod, path, epoch=3)
+    raw = torch.load(path, weights_only=True)  # plain tensors / dicts only
+    assert raw["epoch"] == 3 and "loss_module.model.decoder.log_concentration" in raw["state_dict"]
+    again = type(mod).load_from_checkpoint(path)
+    for (k1, v1), (k2, v2) in zip(mod.state_dict().items(), again.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    assert again.config["loss_module_kwargs"]["beta"] == case["cfg"]["beta"]
+
+
+def test_no_cpu_fallback():
+    from cradle_vae_amd.hip import CradleHipError
+
+    case = gio.load_elbo("tiny")
+    mod = _module(case)
+    b = case["batch"]
+    with pytest.raises(CradleHipError):
+        mod.training_step({k: b[k] for k in ("X", "D", "qc", "cfX", "library_size")}, 0)
+
+
+def test_device_batch_loader_shards_and_gathers():
+    from cradle_vae_amd.data import DeviceBatchLoader, SCRNASeqTensorPerturbationDataset
+
+    g = torch.Generator().manual_seed(0)
+    n, G, T = 103, 8, 5
+    X = torch.poisson(3 * torch.rand(n, G, generator=g))
+    cfX = torch.poisson(3 * torch.rand(n, G, generator=g))
+    D = (torch.rand(n, T, generator=g) < 0.3).float()
+    qc = (torch.rand(n, 1, generator=g) < 0.2).float()
+    ds = SCRNASeqTensorPerturbationDataset(X, D, qc, cfX, ids=[f"c{i}" for i in range(n)])
+    assert torch.equal(ds.get_dosage_obs_per_dim(), (D != 0).sum(0)) and torch.equal(ds.get_qc_obs_per_dim(), (qc != 0).sum(0))
+    s = ds[7]
+    assert float(s["library_size"]) == float(X[7].sum()) and torch.equal(s["cfX"], cfX[7])
+    assert list(ds.convert_idx_to_ids(np.array([0, 2]))) == ["c0", "c2"]
+    # unshuffled, one rank: every cell once, in order
+    seen = []
+    for b in DeviceBatchLoader(ds, batch_size=16):
+        i = b["idx"]
+        assert torch.equal(b["X"], X[i]) and torch.equal(b["D"], D[i]) and torch.equal(b["library_size"], X[i].sum(1))
+        seen.append(i)
+    assert torch.equal(torch.cat(seen), torch.arange(n))
+    # shuffled, two ranks: disjoint, equal length, same permutation on both ranks, new order per epoch
+    per_rank = []
+    for r in range(2):
+        ld = DeviceBatchLoader(ds, batch_size=10, shuffle=True, drop_last=True, seed=4, rank=r, world_size=2)
+        e0 = torch.cat([b["idx"] for b in ld])
+        e1 = torch.cat([b["idx"] for b in ld])
+        assert len(e0) == len(ld) * 10 == 50 and not torch.equal(e0, e1)
+        per_rank.append(e0)
+    assert len(set(per_rank[0].tolist()) & set(per_rank[1].tolist())) == 0
+    # evaluation sharding keeps every cell
+    ev = [torch.cat([b["idx"] for b in DeviceBatchLoader(ds, 16, rank=r, world_size=2)]) for r in range(2)]
+    assert sorted(torch.cat(ev).tolist()) == list(range(n))
+
+
+def test_compat_alias_package_resolves_reference_import_paths():
+    """`import cradle_vae...` with <repo>/compat on the path lands on this build (run in a child
+    process so that the alias never shadows the reference for the golden-fixture tooling)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "from cradle_vae import models, data\n"
+        "from cradle_vae.models.utils.perturbation_lightning_module import TrainConfigPerturbationLightningModule as T\n"
+        "from cradle_vae.models.utils.predictor import PerturbationPlatedPredictor\n"
+        "from cradle_vae.models.cradle_vae.guides.correlated_normal_guide import cradle_vae_CorrelatedNormalGuide\n"
+        "from cradle_vae.analysis.average_treatment_effects import estimate_model_average_treatment_effect\n"
+        "from cradle_vae.data.utils.perturbation_dataset import SCRNASeqTensorPerturbationDataset\n"
+        "from cradle_vae.data.utils.perturbation_datamodule import ObservationNormalizationStatistics\n"
+        "import cradle_vae_amd.models as m\n"
+        "assert models.cradle_vae_Model is m.cradle_vae_Model and T.__module__.startswith('cradle_vae_amd')\n"
+        "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "compat"), root]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
