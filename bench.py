@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--shape", default="norman")
     ap.add_argument("--step-impl", default="auto", choices=["auto", "fused", "modular"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph instead of launching its kernels on three streams")
     args = ap.parse_args()
 
     from cradle_vae_amd import hip, ops
@@ -168,6 +169,13 @@ def main():
 
     stepper = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=world)
 
+    if stepper.fused is not None:
+        stepper.fused.use_graph = args.graph
+        # K1 is timed with HIP events in every step (rank 0): the step then replays as two graphs
+        # with K1 launched between them.  Switched on before the warm-up so that the timed
+        # region holds no graph capture.
+        stepper.fused.k1_events = [] if rank == 0 else None
+
     def one_step(i):
         return stepper(batch, n_particles=shape.n_particles)
 
@@ -178,8 +186,8 @@ def main():
         dist.barrier()
     ops.KERNEL_TIMERS.clear()
     ops.KERNEL_TIMING = True
-    if stepper.fused is not None:
-        stepper.fused.k1_events = []
+    if stepper.fused is not None and stepper.fused.k1_events is not None:
+        stepper.fused.k1_events.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -239,7 +247,8 @@ def main():
             "config": {
                 "workload": f"{shape.name}: ELBO fwd+bwd+clip+Adam, N={N} cells/GPU, P={P}, G={G}, "
                             f"T={shape.n_treatments}, L={shape.n_latent}, H={shape.decoder_n_hidden}",
-                "step_impl": stepper.impl, "decoder_variants_per_cell": V, "parallelism": f"dp{world}",
+                "step_impl": stepper.impl, "hip_graph": bool(stepper.fused is not None and stepper.fused.use_graph),
+                "decoder_variants_per_cell": V, "parallelism": f"dp{world}",
                 "loss": float(loss),
             },
             "roofline": roofline,

@@ -133,13 +133,17 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int row, int col, 
 // 2x2 arrangement of 32x32 tiles, so each SIMD holds two waves whose LDS round trips
 // (write -> barrier -> fragment read) hide behind the other's MFMA chain; their partial
 // accumulators are summed through LDS before the epilogue.
-template <bool A_KMAJOR, bool B_KMAJOR, int TM, int TN, int BK, int D, int WK, bool VEC>
-__global__ __launch_bounds__(256 * WK) void gemm_f32_kernel(const GemmParams p) {
-  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, NT = 256 * WK;
+// WS = 1: a single 32x32 wave tile per K group (BM = BN = 32 * T), for problems with too few
+// 64x64 tiles to occupy the chip: with WK = 4 the four waves of a workgroup split every K step
+// four ways, so a 1050 x 400 x 400 product runs on ~430 workgroups x 4 SIMDs instead of 119.
+template <bool A_KMAJOR, bool B_KMAJOR, int TM, int TN, int BK, int D, int WK, bool VEC, int WS = 2>
+__global__ __launch_bounds__(64 * WS * WS * WK) void gemm_f32_kernel(const GemmParams p) {
+  constexpr int BM = WS * TM * 32, BN = WS * TN * 32, NT = 64 * WS * WS * WK;
   using LA = TileLoader<A_KMAJOR, BM, BK, NT>;
   using LB = TileLoader<B_KMAJOR, BN, BK, NT>;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (LA::lds_floats() + LB::lds_floats())];
   constexpr int STAGE = LA::lds_floats() + LB::lds_floats();
+  constexpr int RED = (WK - 1) * WS * WS * TM * TN * 16 * 64;  // K-group reduction scratch (reuses the stages)
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE > RED ? 2 * STAGE : RED];
   auto As = [&](int buf) { return lds + buf * STAGE; };
   auto Bs = [&](int buf) { return lds + buf * STAGE + LA::lds_floats(); };
 
@@ -157,8 +161,8 @@ __global__ __launch_bounds__(256 * WK) void gemm_f32_kernel(const GemmParams p) 
   const int tile_m = wg / tiles_n, tile_n = wg % tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
 
-  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, kgroup = threadIdx.x >> 8;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % (WS * WS), kgroup = (threadIdx.x >> 6) / (WS * WS);
+  const int wm = wave / WS, wn = wave % WS;
   const int li = lane & 31, lh = lane >> 5;
 
   const int k_tiles = (p.K + BK - 1) / BK;
@@ -221,11 +225,11 @@ __global__ __launch_bounds__(256 * WK) void gemm_f32_kernel(const GemmParams p) 
     }
   }
 
-  if (WK > 1) {  // sum the K halves: waves 4-7 park their accumulators in LDS, waves 0-3 add them
-    static_assert(WK == 1 || 2 * STAGE >= 4 * TM * TN * 16 * 64, "LDS too small for the K-half reduction");
+  if (WK > 1) {  // sum the K groups: groups 1.. park their accumulators in LDS, group 0 adds them
+    constexpr int PER_WAVE = TM * TN * 16 * 64;
     __syncthreads();
-    float* red = lds + (size_t)wave * (TM * TN * 16 * 64);
-    if (kgroup == 1) {
+    if (kgroup > 0) {
+      float* red = lds + (size_t)((kgroup - 1) * WS * WS + wave) * PER_WAVE;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -234,13 +238,17 @@ __global__ __launch_bounds__(256 * WK) void gemm_f32_kernel(const GemmParams p) 
           for (int e = 0; e < 16; ++e) red[((i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
     }
     __syncthreads();
-    if (kgroup == 1) return;
+    if (kgroup > 0) return;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int g = 0; g < WK - 1; ++g) {
+      const float* red = lds + (size_t)(g * WS * WS + wave) * PER_WAVE;
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] += red[((i * TN + j) * 16 + e) * 64 + lane];
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += red[((i * TN + j) * 16 + e) * 64 + lane];
+    }
   }
 
   // ---- epilogue.  acc element e of lane: row = (e&3) + 8*(e>>2) + 4*lh, col = li
@@ -254,42 +262,60 @@ __global__ __launch_bounds__(256 * WK) void gemm_f32_kernel(const GemmParams p) 
       for (int e = 0; e < 16; ++e) {
         const int row = row0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (row >= p.M) continue;
-        if (p.splitk > 1) p.partial[((int64_t)blockIdx.z * p.M + row) * Np + col] = acc[i][j][e];
+        if (p.splitk > 1) p.partial[(int64_t)blockIdx.z * p.slab + (int64_t)row * Np + col] = acc[i][j][e];
         else epilogue(p, row, col, acc[i][j][e]);
       }
     }
 }
 
-// Sums the split-K partial tiles (fixed order: deterministic) and applies the epilogue.
+// Sums the split-K partial tiles (fixed order: deterministic) and applies the epilogue.  Every
+// thread takes four consecutive elements of the flattened (M, Np) result: the slabs are padded to
+// a multiple of four floats, so the partials stream in as 16-byte loads whatever Np is.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
   const int Np = p.N + (p.extra_col ? 1 : 0);
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)p.M * Np) return;
-  const int row = idx / Np, col = idx % Np;
-  float v = 0.f;
-  for (int z = 0; z < p.splitk; ++z) v += p.partial[((int64_t)z * p.M + row) * Np + col];
-  epilogue(p, row, col, v);
+  const int64_t total = (int64_t)p.M * Np;
+  const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (idx >= total) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < p.splitk; ++z) {
+    const float4 t = *reinterpret_cast<const float4*>(p.partial + (int64_t)z * p.slab + idx);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  int row = (int)(idx / Np), col = (int)(idx % Np);
+  const float vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (idx + e < total) epilogue(p, row, col, vals[e]);
+    if (++col == Np) { col = 0; ++row; }
+  }
 }
 
+// ws = 2: 2x2 waves per K group (tile 64*tm x 64*tn); ws = 1: one wave per K group (tile 32*tm x 32*tn)
 template <bool AK, bool BKM>
-static bool launch_cfg(const GemmParams& p, int tm, int tn, int bk, int depth, int wk, bool vec, dim3 grid,
+static bool launch_cfg(const GemmParams& p, int ws, int tm, int tn, int bk, int depth, int wk, bool vec, dim3 grid,
                        hipStream_t s) {
-#define CRADLE_GEMM_CASE(TM_, TN_, BK_, D_, WK_)                                                              \
-  if (tm == TM_ && tn == TN_ && bk == BK_ && depth == D_ && wk == WK_) {                                       \
+#define CRADLE_GEMM_CASE(WS_, TM_, TN_, BK_, D_, WK_)                                                          \
+  if (ws == WS_ && tm == TM_ && tn == TN_ && bk == BK_ && depth == D_ && wk == WK_) {                          \
+    constexpr int NT_ = 64 * WS_ * WS_ * WK_;                                                                  \
     if (vec)                                                                                                   \
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, BK_, D_, WK_, true>), grid, dim3(256 * WK_), 0, s, p);  \
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, BK_, D_, WK_, true, WS_>), grid, dim3(NT_), 0, s, p);  \
     else                                                                                                       \
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, BK_, D_, WK_, false>), grid, dim3(256 * WK_), 0, s, p); \
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, TM_, TN_, BK_, D_, WK_, false, WS_>), grid, dim3(NT_), 0, s, p); \
     return true;                                                                                               \
   }
-  CRADLE_GEMM_CASE(2, 2, 16, 2, 1)
-  CRADLE_GEMM_CASE(1, 1, 16, 2, 1)
-  CRADLE_GEMM_CASE(1, 1, 16, 4, 1)
-  CRADLE_GEMM_CASE(1, 1, 32, 2, 1)
-  CRADLE_GEMM_CASE(1, 1, 32, 2, 2)
-  CRADLE_GEMM_CASE(1, 1, 32, 4, 2)
-  CRADLE_GEMM_CASE(1, 2, 32, 2, 2)
-  CRADLE_GEMM_CASE(2, 2, 32, 2, 2)
+  CRADLE_GEMM_CASE(2, 2, 2, 16, 2, 1)
+  CRADLE_GEMM_CASE(2, 1, 1, 16, 2, 1)
+  CRADLE_GEMM_CASE(2, 1, 1, 16, 4, 1)
+  CRADLE_GEMM_CASE(2, 1, 1, 32, 2, 1)
+  CRADLE_GEMM_CASE(2, 1, 1, 32, 2, 2)
+  CRADLE_GEMM_CASE(2, 1, 1, 32, 4, 2)
+  CRADLE_GEMM_CASE(2, 1, 2, 32, 2, 2)
+  CRADLE_GEMM_CASE(2, 2, 2, 32, 2, 2)
+  CRADLE_GEMM_CASE(1, 1, 1, 32, 2, 4)
+  CRADLE_GEMM_CASE(1, 1, 1, 32, 4, 4)
+  CRADLE_GEMM_CASE(1, 1, 1, 64, 2, 4)
+  CRADLE_GEMM_CASE(1, 1, 2, 32, 2, 4)
+  CRADLE_GEMM_CASE(1, 2, 2, 32, 2, 4)
 #undef CRADLE_GEMM_CASE
   return false;
 }
@@ -297,11 +323,12 @@ static bool launch_cfg(const GemmParams& p, int tm, int tn, int bk, int depth, i
 int64_t gemm_workspace_floats(int layout, int M, int N, int K, int extra_col) {
   (void)layout;
   (void)K;
-  return (int64_t)32 * M * (N + (extra_col ? 1 : 0));  // worst case split factor 32
+  return (int64_t)32 * (((int64_t)M * (N + (extra_col ? 1 : 0)) + 3) & ~int64_t(3));  // worst case split factor 32
 }
 
 // manual override for tuning runs (tools/bench_gemm.py): -1 = automatic
-static int g_tune_tm = -1, g_tune_tn = -1, g_tune_bk = -1, g_tune_splitk = -1, g_tune_depth = -1, g_tune_wk = -1;
+static int g_tune_tm = -1, g_tune_tn = -1, g_tune_bk = -1, g_tune_splitk = -1, g_tune_depth = -1, g_tune_wk = -1,
+           g_tune_ws = 2;
 
 // Host-side dispatch.  `workspace` lets the problem split along K (partials + reducer).
 int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_floats, hipStream_t stream) {
@@ -309,24 +336,38 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
   CRADLE_CHECK_ARG(p.A && p.B && p.C && p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad arguments M=%d N=%d K=%d", p.M, p.N, p.K);
   CRADLE_CHECK_ARG(!p.extra_col || layout == 2, "gemm: the ones-column output needs the TN layout");
   const int Np = p.N + (p.extra_col ? 1 : 0);
-  auto tiles = [&](int tm_, int tn_) { return (int64_t)((p.M + 64 * tm_ - 1) / (64 * tm_)) * ((Np + 64 * tn_ - 1) / (64 * tn_)); };
-  // Heuristics from tools/tune_gemm.py sweeps on MI355X at the ELBO step's shapes: 64x64 tiles
-  // (four waves, one 32x32 MFMA tile each) win everywhere below ~1000 tiles of 128x128 because a
-  // few hundred large tiles leave whole rounds of CUs idle; long-K problems are split along K
-  // until ~2048 workgroups are in flight, never below 16 K-steps (256 values of k) per split.
-  int tm = 1, tn = 1, bk = 16, depth = 4, wk = 1;
-  if (tiles(2, 2) >= 1024) { tm = 2; tn = 2; depth = 2; }
-  if (g_tune_tm > 0) { tm = g_tune_tm; tn = g_tune_tn; bk = g_tune_bk; depth = g_tune_depth; wk = g_tune_wk; }
-  const int64_t ntiles = tiles(tm, tn);
+  auto tiles_ws = [&](int ws_, int tm_, int tn_) {
+    const int bm = 32 * ws_ * tm_, bn = 32 * ws_ * tn_;
+    return (int64_t)((p.M + bm - 1) / bm) * ((Np + bn - 1) / bn);
+  };
+  auto tiles = [&](int tm_, int tn_) { return tiles_ws(2, tm_, tn_); };
+  // Heuristics from tools/tune_gemm.py sweeps on MI355X at the ELBO step's shapes:
+  //  * 64x64 tiles (four waves, one 32x32 MFMA tile each, BK 16) win everywhere below ~1000 tiles of
+  //    128x128, because a few hundred large tiles leave whole rounds of CUs idle; long-K problems
+  //    are split along K until ~2048 workgroups are in flight, never below 16 K-steps per split;
+  //  * small problems (up to ~600 tiles of 64x64 and ~5 GFLOP: the embedding / qc encoders, the
+  //    hidden layers, most weight gradients) run 15-45 % faster on 32x32 tiles whose four waves
+  //    split each 32-wide K step between them: 4x the workgroups and a quarter of the MFMA
+  //    chain per wave; split along K towards ~768 workgroups, at least 8 K-steps per split.
+  int ws = 2, tm = 1, tn = 1, bk = 16, depth = 2, wk = 1;
+  const double flops = 2.0 * p.M * (double)Np * p.K;
+  if (tiles(2, 2) >= 1024) { tm = 2; tn = 2; }
+  else if (tiles(1, 1) <= 600 && flops <= 5e9) { ws = 1; bk = 32; wk = 4; }
+  if (g_tune_tm > 0) { ws = g_tune_ws; tm = g_tune_tm; tn = g_tune_tn; bk = g_tune_bk; depth = g_tune_depth; wk = g_tune_wk; }
+  const int64_t ntiles = tiles_ws(ws, tm, tn);
   const int k_tiles = (p.K + bk - 1) / bk;
   int splitk = 1;
-  if (workspace && ntiles < 2048) {
+  if (workspace && ws == 1 && ntiles < 768) {
+    splitk = (int)min((int64_t)8, (768 + ntiles - 1) / ntiles);
+    splitk = max(1, min(splitk, k_tiles / 8));
+  } else if (workspace && ws == 2 && ntiles < 2048) {
     splitk = (int)min((int64_t)16, (2048 + ntiles - 1) / ntiles);
     splitk = max(1, min(splitk, k_tiles / 16));
   }
   if (g_tune_splitk > 0) splitk = g_tune_splitk;
-  if (!workspace) splitk = 1;
-  while (splitk > 1 && (int64_t)splitk * p.M * Np > workspace_floats) --splitk;
+  if (!workspace || (uintptr_t)workspace % 16 != 0) splitk = 1;
+  p.slab = ((int64_t)p.M * Np + 3) & ~int64_t(3);
+  while (splitk > 1 && (int64_t)splitk * p.slab > workspace_floats) --splitk;
   p.k_tiles_per_split = (k_tiles + splitk - 1) / splitk;
   splitk = (k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
   p.splitk = splitk;
@@ -344,14 +385,14 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
   else aligned = aligned && p.M % 4 == 0 && p.N % 4 == 0 && p.M >= 4 && p.N >= 4;
   dim3 grid((unsigned)ntiles, 1, (unsigned)splitk);
   bool ok;
-  if (layout == 0) ok = launch_cfg<true, true>(p, tm, tn, bk, depth, wk, aligned, grid, stream);
-  else if (layout == 1) ok = launch_cfg<true, false>(p, tm, tn, bk, depth, wk, aligned, grid, stream);
-  else ok = launch_cfg<false, false>(p, tm, tn, bk, depth, wk, aligned, grid, stream);
-  CRADLE_CHECK_ARG(ok, "gemm: no kernel for tile %dx%d bk %d depth %d wk %d", tm, tn, bk, depth, wk);
+  if (layout == 0) ok = launch_cfg<true, true>(p, ws, tm, tn, bk, depth, wk, aligned, grid, stream);
+  else if (layout == 1) ok = launch_cfg<true, false>(p, ws, tm, tn, bk, depth, wk, aligned, grid, stream);
+  else ok = launch_cfg<false, false>(p, ws, tm, tn, bk, depth, wk, aligned, grid, stream);
+  CRADLE_CHECK_ARG(ok, "gemm: no kernel for ws %d tile %dx%d bk %d depth %d wk %d", ws, tm, tn, bk, depth, wk);
   CRADLE_CHECK_LAUNCH("gemm_f32_kernel");
   if (splitk > 1) {
-    const int64_t total = (int64_t)p.M * Np;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    const int64_t quads = (p.slab + 3) / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
     CRADLE_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return CRADLE_OK;
@@ -367,6 +408,8 @@ extern "C" {
 void cradle_gemm_tune(int tm, int tn, int bk, int depth, int wk, int splitk) {
   cradle::g_tune_tm = tm; cradle::g_tune_tn = tn; cradle::g_tune_bk = bk; cradle::g_tune_depth = depth;
   cradle::g_tune_wk = wk; cradle::g_tune_splitk = splitk;
+  cradle::g_tune_ws = 2;
+  if (wk == 4) cradle::g_tune_ws = 1;  // the four-K-group kernels are the single-wave-tile ones
 }
 
 // Public descriptor (include/cradle_hip.h: cradle_gemm_desc).  Field order is ABI.

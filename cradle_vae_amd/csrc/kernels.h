@@ -31,6 +31,7 @@ struct GemmParams {
   uint32_t a_bytes, b_bytes;  // filled by gemm_f32: operand extents for the buffer descriptors
   int splitk;             // filled by gemm_f32
   float* partial;
+  int64_t slab;           // floats between the partial results of consecutive K splits (multiple of 4)
   int k_tiles_per_split;
 };
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };

@@ -14,6 +14,9 @@
 //   (v)   the lgamma terms of the likelihood are evaluated per (cell, gene), not per particle;
 //   (vi)  the one-hot block of the embedding encoder's first layer is a table lookup;
 //   (vii) every matmul(D, .) / matmul(qc, .) is a gather / scatter over <= kmax non-zeros per cell.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -390,25 +393,23 @@ int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* d) {
   return carve(*d, nullptr, w);
 }
 
-int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
-  CRADLE_CHECK_ARG(dp, "elbo_step: null descriptor");
-  const cradle_step_desc& d = *dp;
-  int rc = check_desc(d);
-  if (rc) return rc;
-  Work w;
-  const int64_t need = carve(d, d.workspace, w);
-  CRADLE_CHECK_ARG(d.workspace_bytes >= need, "elbo_step: workspace has %lld bytes, needs %lld",
-                   (long long)d.workspace_bytes, (long long)need);
+}  // extern "C"
+
+namespace {
+
+// The step in three phases so that the NB-likelihood launch (K1) can sit between two captured
+// graphs when the caller wants HIP events around it (events recorded inside a capture carry no
+// timing).  No side stream is active at either phase boundary.
+enum { PH_PRE = 1, PH_K1 = 2, PH_POST = 4, PH_ALL = 7 };
+
+int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   const int P = d.P, N = d.N, T = d.T, L = d.L, Q = d.Q, G = d.G, He = d.He, Hm = d.Hm, Hd = d.Hd;
   const int PP = 2 * P, PN = P * N, PT = PP * T;
-  StreamSet* ss = nullptr;
-  rc = get_streams(&ss);
-  if (rc) return rc;
-  Ctx c;
-  c.st[0] = s; c.st[1] = ss->side[0]; c.st[2] = ss->side[1];
-  for (int i = 0; i < 3; ++i) c.splitk[i] = w.splitk[i];
-  c.ev = ss->ev;
-  hipStream_t s1 = c.st[1], s2 = c.st[2];
+  int rc = 0;
+  hipStream_t s = c.st[0], s1 = c.st[1], s2 = c.st[2];
+  const float* Wenc0 = d.enc.W[0];
+  const int64_t ldenc = (int64_t)G + 2 * L;
+  const float* Wd0 = d.dec.W[0];
 #define STEP(call)        \
   do {                    \
     rc = (call);          \
@@ -416,13 +417,17 @@ int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
     if (c.rc) return c.rc; \
   } while (0)
 
+  if (phases & PH_PRE) {
   // ================================================================== forward
   // stream 1: log-standardise X and cfX, x Wx^T.   stream 2: q(qc_E) and the per-gene constants.
   // stream 0 (caller's): dosage plan, q(M), q(E|M), gathers -- then joins both.
   c.after(1, 0);
   c.after(2, 0);
-  const float* Wenc0 = d.enc.W[0];
-  const int64_t ldenc = (int64_t)G + 2 * L;
+  // the dosage plan and the per-cell weights depend on the batch only: first thing on stream 1,
+  // so that stream 0 starts with q(M) / q(E|M) straight away and meets the plan at the gather
+  STEP(build_dosage_plan(d.D, N, T, w.plan, s1));
+  STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, s1));
+  c.after(0, 1);
   STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s1));
   c.gemm(GEMM_NT, gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G), 1);  // x Wx^T, X and cfX
 
@@ -438,11 +443,8 @@ int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
   if (c.rc) return c.rc;
   STEP(qce_fwd(w.headsq, d.eps_qc_E, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.Sq, w.qsum, PP, P, Q, L, s2));
   c.gemm(GEMM_NT, gp(w.qcE, L, Wenc0 + G + L, ldenc, w.vq, He, PP * Q, He, L), 2);  // qc_E Wqc^T
-  const float* Wd0 = d.dec.W[0];
   c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L), 2);        // bad-variant shift per particle
 
-  STEP(build_dosage_plan(d.D, N, T, w.plan, s));
-  STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, s));
   STEP(mask_fwd(d.q_mask_logits, d.u_mask, d.p_mask_probs, d.temperature, w.mask, w.soft, w.Smask, PP, T, L, s));
   STEP(transpose_cols(d.emb.W[0], L + T, Hm, L, T, w.W0tT, s));
   {  // layer 0: LeakyReLU(mask Wm^T + W_onehot[:, t] + b)
@@ -478,6 +480,8 @@ int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
   trunk_fwd(c, d.dec, PN, Hd, w.yd, w.rd);
   head_fwd(c, d.dec, PN, Hd, G, w.yd[d.dec.n_layers - 1], w.logits);
   if (c.rc) return c.rc;
+  }  // PH_PRE
+  if (phases & PH_K1) {
   if (!d.compute_grads) {
     if (d.ev_k1_begin) (void)hipEventRecord((hipEvent_t)d.ev_k1_begin, s);
     STEP(cradle_nb_logprob_fwd(w.logits, G, d.X, G, d.library_size, w.gene_consts, w.recon, P, N, G, s));
@@ -487,6 +491,8 @@ int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
                                          w.recon, d.d_log_concentration, 0, w.nbws, w.nbws_floats, P, N, G,
                                          d.ev_k1_begin, d.ev_k1_end, s));
   }
+  }  // PH_K1
+  if (!(phases & PH_POST)) return CRADLE_OK;
   STEP(finalize_loss(w.recon, w.cp.wrec, w.ltz, w.klrow, w.Smask, w.SE, w.Sq, w.cp.cw, w.cp.cwq, d.beta, P, N, T, Q,
                      d.out, s));
   if (!d.compute_grads) return CRADLE_OK;
@@ -568,6 +574,187 @@ int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
   c.after(0, 2);
   if (c.rc) return c.rc;
 #undef STEP
+  return CRADLE_OK;
+}
+
+int prepare(const cradle_step_desc* dp, Work& w, Ctx& c, hipStream_t main) {
+  CRADLE_CHECK_ARG(dp, "elbo_step: null descriptor");
+  const cradle_step_desc& d = *dp;
+  int rc = check_desc(d);
+  if (rc) return rc;
+  const int64_t need = carve(d, d.workspace, w);
+  CRADLE_CHECK_ARG(d.workspace_bytes >= need, "elbo_step: workspace has %lld bytes, needs %lld",
+                   (long long)d.workspace_bytes, (long long)need);
+  StreamSet* ss = nullptr;
+  rc = get_streams(&ss);
+  if (rc) return rc;
+  c.st[0] = main; c.st[1] = ss->side[0]; c.st[2] = ss->side[1];
+  for (int i = 0; i < 3; ++i) c.splitk[i] = w.splitk[i];
+  c.ev = ss->ev;
+  return CRADLE_OK;
+}
+
+// ---- HIP-graph replay of the step ---------------------------------------------------------
+// The step is ~110 launches plus ~40 event operations; enqueueing them costs the host about as
+// long as the GPU needs to run them.  The graphed entry captures the same launch sequence once
+// per distinct descriptor (all pointers, sizes and scalars are baked into the nodes) on a
+// library-owned stream and replays it afterwards.
+constexpr int kGraphSlots = 48;
+// Each slot owns the fork/join events its captures recorded and keeps the captured graphs alive
+// next to their executables: an event recorded during a capture refers to nodes of that graph,
+// so neither is shared with, or outlives into, another capture.
+struct GraphSlot {
+  bool used = false;
+  bool split = false;
+  cradle_step_desc key;
+  hipGraph_t graph[2] = {nullptr, nullptr};
+  hipGraphExec_t exec[2] = {nullptr, nullptr};
+  hipEvent_t ev[kMaxEvents];
+  int nev = 0;
+  uint64_t stamp = 0;
+};
+struct GraphSet {
+  bool ready = false;
+  hipStream_t cs;
+  hipEvent_t ein, eout;
+  GraphSlot slot[kGraphSlots];
+  uint64_t clock = 0;
+};
+GraphSet g_graphs[16];
+
+bool graph_debug() {
+  static const bool on = getenv("CRADLE_GRAPH_DEBUG") != nullptr;
+  return on;
+}
+#define GDBG(...) do { if (graph_debug()) { fprintf(stderr, "[cradle graph] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
+// A slot whose capture failed is abandoned, not destroyed, and slots are never evicted: on
+// ROCm 7.2 destroying graph executables that had been launched (hipGraphExecDestroy after a
+// stream synchronise) was followed by a crash inside a later hipGraphLaunch.  The cache is
+// therefore append-only and bounded; once it is full, unknown descriptors launch eagerly.
+void abandon_slot(GraphSlot& sl) {
+  for (int i = 0; i < 2; ++i) sl.exec[i] = nullptr, sl.graph[i] = nullptr;
+  sl.nev = 0;
+  sl.used = false;
+}
+
+int capture(const cradle_step_desc& d, Work& w, Ctx& c, int phases, hipStream_t cs, hipGraph_t* gout,
+            hipGraphExec_t* out) {
+  GDBG("begin capture phases=%d", phases);
+  if (hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    cradle_set_error("elbo_step: hipStreamBeginCapture failed");
+    return CRADLE_ERR_HIP;
+  }
+  const int rc = run_step(d, w, c, phases);
+  hipGraph_t g = nullptr;
+  GDBG("run_step rc=%d, end capture", rc);
+  const hipError_t e = hipStreamEndCapture(cs, &g);
+  GDBG("end capture -> %d graph %p", (int)e, (void*)g);
+  if (rc) {
+    if (g) (void)hipGraphDestroy(g);
+    return rc;
+  }
+  if (e != hipSuccess || !g) {
+    cradle_set_error("elbo_step: hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    return CRADLE_ERR_HIP;
+  }
+  *gout = g;  // owned by the slot from here on
+  const hipError_t ei = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  GDBG("instantiate -> %d exec %p", (int)ei, (void*)*out);
+  if (ei != hipSuccess) {
+    cradle_set_error("elbo_step: hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+    return CRADLE_ERR_HIP;
+  }
+  return CRADLE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
+  Work w;
+  Ctx c;
+  int rc = prepare(dp, w, c, s);
+  if (rc) return rc;
+  return run_step(*dp, w, c, PH_ALL);
+}
+
+// Same result as cradle_elbo_step, replayed from a HIP graph.  `*recaptured` (may be NULL) is set
+// to 1 when this call had to capture (first use of this descriptor, or eviction from the 8-slot
+// cache).  With ev_k1_begin/end set, K1 is launched eagerly between two graphs so that the
+// events carry timing.  Not thread-safe; work is ordered after / before the caller's stream `s`.
+int cradle_elbo_step_graphed(const cradle_step_desc* dp, hipStream_t s, int* recaptured) {
+  if (recaptured) *recaptured = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    cradle_set_error("elbo_step: cannot identify the current device");
+    return CRADLE_ERR_HIP;
+  }
+  GraphSet& gs = g_graphs[dev];
+  if (!gs.ready) {
+    if (hipStreamCreateWithFlags(&gs.cs, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&gs.ein, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&gs.eout, hipEventDisableTiming) != hipSuccess) {
+      cradle_set_error("elbo_step: graph stream/event creation failed");
+      return CRADLE_ERR_HIP;
+    }
+    gs.ready = true;
+  }
+  Work w;
+  Ctx c;
+  int rc = prepare(dp, w, c, gs.cs);
+  if (rc) return rc;
+  const cradle_step_desc& d = *dp;
+  cradle_step_desc key = d;
+  key.ev_k1_begin = key.ev_k1_end = nullptr;
+  const bool split = d.ev_k1_begin || d.ev_k1_end;
+  GraphSlot* sl = nullptr;
+  for (auto& cand : gs.slot)
+    if (cand.used && cand.split == split && memcmp(&cand.key, &key, sizeof(key)) == 0) sl = &cand;
+  if (!sl) {
+    for (auto& cand : gs.slot)
+      if (!cand.used && !cand.exec[0]) { sl = &cand; break; }
+    if (!sl) {  // cache full: launch this descriptor's kernels directly on the caller's stream
+      GDBG("cache full: eager launch");
+      c.st[0] = s;
+      return run_step(d, w, c, PH_ALL);
+    }
+    for (sl->nev = 0; sl->nev < kMaxEvents; ++sl->nev)
+      if (hipEventCreateWithFlags(&sl->ev[sl->nev], hipEventDisableTiming) != hipSuccess) {
+        abandon_slot(*sl);
+        cradle_set_error("elbo_step: event creation failed");
+        return CRADLE_ERR_HIP;
+      }
+    c.ev = sl->ev;
+    rc = capture(d, w, c, split ? PH_PRE : PH_ALL, gs.cs, &sl->graph[0], &sl->exec[0]);
+    if (!rc && split) rc = capture(d, w, c, PH_POST, gs.cs, &sl->graph[1], &sl->exec[1]);
+    if (rc) {
+      abandon_slot(*sl);
+      return rc;
+    }
+    sl->used = true;
+    sl->split = split;
+    sl->key = key;
+    if (recaptured) *recaptured = 1;
+  }
+  sl->stamp = ++gs.clock;
+  GDBG("launch slot %d split=%d", (int)(sl - gs.slot), (int)split);
+  bool ok = hipEventRecord(gs.ein, s) == hipSuccess && hipStreamWaitEvent(gs.cs, gs.ein, 0) == hipSuccess;
+  GDBG("fork ok=%d, launching exec %p", (int)ok, (void*)sl->exec[0]);
+  ok = ok && hipGraphLaunch(sl->exec[0], gs.cs) == hipSuccess;
+  GDBG("launched ok=%d", (int)ok);
+  if (ok && split) {
+    rc = run_step(d, w, c, PH_K1);
+    if (rc) return rc;
+    ok = hipGraphLaunch(sl->exec[1], gs.cs) == hipSuccess;
+  }
+  ok = ok && hipEventRecord(gs.eout, gs.cs) == hipSuccess && hipStreamWaitEvent(s, gs.eout, 0) == hipSuccess;
+  GDBG("joined ok=%d", (int)ok);
+  if (!ok) {
+    cradle_set_error("elbo_step: graph launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return CRADLE_ERR_HIP;
+  }
   return CRADLE_OK;
 }
 

@@ -143,9 +143,46 @@ class FusedElboStep:
         self._noise = None
         self._calls = 0
         self._shape_key = None
+        self._states = {}
         self.k1_events = None  # list collecting hip.EventPair around K1 when profiling (bench.py)
+        # Optional HIP-graph replay (cradle_elbo_step_graphed).  Off by default: on ROCm 7.2 / MI355X
+        # the replay of this multi-branch graph measured slower (1.52 ms) than launching its kernels
+        # on three streams (1.35 ms) -- the step is GPU-bound, not enqueue-bound.  The graph bakes every
+        # pointer in, so batches arriving at changing addresses are first copied into persistent
+        # staging buffers (switched on automatically once re-captures keep happening).
+        self.use_graph = False
+        self.stage_inputs = False
+        self._staged = None
+        self._recaptures = 0
 
     # ------------------------------------------------------------------ descriptor
+    def _select_state(self, P, N):
+        """Per-(P, N) descriptor, outputs, noise and staging buffers are kept, so that alternating
+        shapes (training / validation batches) come back to the pointers their graphs were captured with."""
+        key = (P, N, self.arena.base)
+        st = self._states.get(key)
+        if st is None:
+            if len(self._states) >= 4:
+                self._states.pop(next(iter(self._states)))
+            self.desc = hip.StepDesc()
+            self._staged = None
+            self._fill_static(P, N)
+            st = dict(desc=self.desc, out=self.out, flags=self.flags, noise=self._noise, bufs=self._bufs, staged=None)
+            self._states[key] = st
+        else:
+            if self._shape_key != key:
+                self._states_save()
+            self.desc, self.out, self.flags, self._noise, self._bufs, self._staged = (
+                st["desc"], st["out"], st["flags"], st["noise"], st["bufs"], st["staged"])
+        self._shape_key = key
+        if self.desc.workspace != self.workspace.data_ptr():  # the shared workspace grew meanwhile
+            self.desc.workspace, self.desc.workspace_bytes = self.workspace.data_ptr(), self.workspace.numel() * 4
+
+    def _states_save(self):
+        st = self._states.get(self._shape_key)
+        if st is not None:
+            st["staged"] = self._staged
+
     def _fill_static(self, P, N):
         lm, d, a = self.lm, self.desc, self.arena
         g, m = lm.guide, lm.model
@@ -187,7 +224,6 @@ class FusedElboStep:
         self._noise = dict(
             u_mask=torch.empty((2 * P, T, L), device=dev), eps_E=torch.empty((2 * P, T, L), device=dev),
             eps_qc_E=torch.empty((2 * P, Q, L), device=dev), eps_z=torch.empty((P, N, L), device=dev))
-        self._shape_key = (P, N, a.base)
 
     def _set_noise(self, noise, cf_noise, gen_plated=None, gen_local=None):
         nz, d = self._noise, self.desc
@@ -210,14 +246,23 @@ class FusedElboStep:
         """Launches the step; returns the (8,) device tensor [loss, 5 loss terms, cf KL, -]."""
         if not self.arena.valid():
             self.arena.rebuild()  # e.g. after module.to(device) or load_state_dict(assign=True)
+            self._states.clear()
             self._shape_key = None
         P, N = n_particles, X.shape[0]
-        if self._shape_key != (P, N, self.arena.base):
-            self._fill_static(P, N)
+        self._states_save()
+        self._select_state(P, N)
         d = self.desc
         if X.shape[1] != d.G or D.shape != (N, d.T) or qc.shape != (N, d.Q) or cfX.shape != X.shape:
             raise hip.CradleHipError("elbo_step: batch tensor shapes do not match the model")
-        self._keep = [t.contiguous().float() for t in (X, cfX, D, qc, library_size.reshape(-1), D_obs_counts, qc_obs_counts)]
+        ins = (X, cfX, D, qc, library_size.reshape(-1), D_obs_counts, qc_obs_counts)
+        if self.use_graph and self.stage_inputs:
+            if self._staged is None or any(a.shape != b.shape for a, b in zip(self._staged, ins)):
+                self._staged = [torch.empty(t.shape, device=X.device, dtype=torch.float32) for t in ins]
+            for dst, src in zip(self._staged, ins):
+                dst.copy_(src)
+            self._keep = self._staged
+        else:
+            self._keep = [t.contiguous().float() for t in ins]
         (d.X, d.cfX, d.D, d.qc, d.library_size, d.D_obs_counts, d.qc_obs_counts) = [hip.ptr(t) for t in self._keep]
         self._set_noise(noise, cf_noise, gen_plated, gen_local)
         d.beta = float(self.lm.beta)
@@ -229,7 +274,16 @@ class FusedElboStep:
             d.ev_k1_begin, d.ev_k1_end = ev.begin, ev.end
         else:
             d.ev_k1_begin, d.ev_k1_end = None, None
-        hip.check(self.lib.cradle_elbo_step(ctypes.byref(d), hip.stream()), "cradle_elbo_step")
+        if self.use_graph:
+            recaptured = ctypes.c_int(0)
+            hip.check(self.lib.cradle_elbo_step_graphed(ctypes.byref(d), hip.stream(), ctypes.byref(recaptured)),
+                      "cradle_elbo_step_graphed")
+            if recaptured.value:
+                self._recaptures += 1
+                if self._recaptures >= 6 and not self.stage_inputs:
+                    self.stage_inputs = True  # input addresses keep changing: pin them
+        else:
+            hip.check(self.lib.cradle_elbo_step(ctypes.byref(d), hip.stream()), "cradle_elbo_step")
         self._calls += 1
         if self._calls == 1 or self._calls % 256 == 0:
             self.check_flags()

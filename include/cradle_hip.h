@@ -183,6 +183,13 @@ typedef struct cradle_step_desc {
 
 int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only the sizes are read */
 int cradle_elbo_step(const cradle_step_desc* desc, cradle_stream_t stream);
+/* Same result, replayed from a HIP graph: the ~110 launches of the step are captured once per
+ * distinct descriptor (every pointer, size and scalar is baked into the graph; up to 48 descriptors
+ * are kept per device, never evicted -- beyond that, unknown descriptors launch eagerly) on a
+ * library-owned stream ordered after/before `stream`.  *recaptured (may
+ * be NULL) reports whether this call had to capture.  With ev_k1_begin/end set, K1 is launched
+ * eagerly between two graphs so that the events carry timing.  Not thread-safe. */
+int cradle_elbo_step_graphed(const cradle_step_desc* desc, cradle_stream_t stream, int* recaptured);
 
 /* ---- K10: gradient-norm clip + Adam over flat arenas -----------------------------------
  * Replaces Lightning's gradient_clip_val (train_norman.py:96; torch clip_grad_norm_) followed by

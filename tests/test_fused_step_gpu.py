@@ -82,3 +82,61 @@ def test_forward_only_matches_training_forward():
             cfX=b["cfX"], condition_values={"library_size": b["library_size"]}, n_particles=cfg["n_particles"],
             noise=case["noise"], cf_noise=case["cf_noise"])
     assert abs(float(loss) - float(loss2)) <= 1e-6 * abs(float(loss))
+
+
+def _step_outputs(fs, case, **kw):
+    b, cfg = case["batch"], case["cfg"]
+    out = fs.run(X=b["X"], D=b["D"], D_obs_counts=b["D_obs_counts"], qc=b["qc"], qc_obs_counts=b["qc_obs_counts"],
+                 cfX=b["cfX"], library_size=b["library_size"], n_particles=cfg["n_particles"], noise=case["noise"],
+                 cf_noise=case["cf_noise"], **kw)
+    torch.cuda.synchronize()
+    return out.clone(), fs.arena.grad.clone()
+
+
+def test_graph_replay_equals_eager_launch():
+    """cradle_elbo_step_graphed (whole-step graph, and the two-graph form with K1 timed eagerly)
+    against cradle_elbo_step; replays, a second batch at new addresses, input staging."""
+    from cradle_vae_amd import hip
+
+    case = gio.load_elbo("mid", torch.float32, DEV)
+    lm = build_loss_module(case)
+    fs = lm._fused_step()
+    fs.use_graph = False
+    out_e, g_e = _step_outputs(fs, case)
+    fs.use_graph = True
+    fs._recaptures = 0
+    for _ in range(3):  # capture, then replays
+        out_g, g_g = _step_outputs(fs, case)
+        assert torch.allclose(out_g, out_e, rtol=1e-6, atol=1e-6)
+        assert float((g_g - g_e).abs().max()) <= 1e-6 * float(g_e.abs().max())
+    assert fs._recaptures == 1
+    fs.k1_events = []
+    out_s, g_s = _step_outputs(fs, case)
+    assert torch.allclose(out_s, out_e, rtol=1e-6, atol=1e-6) and torch.allclose(g_s, g_g, rtol=1e-5, atol=1e-7)
+    assert len(fs.k1_events) == 1 and 0.0 < fs.k1_events[0].elapsed_ms() < 50.0
+    fs.k1_events = None
+    # forward-only graph
+    out_f, _ = _step_outputs(fs, case, compute_grads=False)
+    assert torch.allclose(out_f, out_e, rtol=1e-6, atol=1e-6)
+    # another batch (new addresses, new values) and back: both graphs stay cached
+    case2 = gio.load_elbo("mid", torch.float32, DEV)
+    case2["batch"] = dict(case2["batch"])
+    case2["batch"]["X"] = torch.roll(case2["batch"]["X"], 1, dims=0).contiguous()
+    fs.use_graph = False
+    out2_e, g2_e = _step_outputs(fs, case2)
+    fs.use_graph = True
+    n0 = fs._recaptures
+    out2_g, g2_g = _step_outputs(fs, case2)
+    assert torch.allclose(out2_g, out2_e, rtol=1e-6, atol=1e-6) and fs._recaptures == n0 + 1
+    assert not torch.allclose(out2_g, out_e, rtol=1e-4)
+    out_b, _ = _step_outputs(fs, case)
+    assert torch.allclose(out_b, out_e, rtol=1e-6, atol=1e-6) and fs._recaptures == n0 + 1
+    # staged inputs: addresses never reach the graph, so no further capture after the staging one
+    fs.stage_inputs = True
+    out_st, g_st = _step_outputs(fs, case2)
+    n1 = fs._recaptures
+    out_st1, _ = _step_outputs(fs, case)
+    assert fs._recaptures == n1
+    assert torch.allclose(out_st, out2_e, rtol=1e-6, atol=1e-6) and torch.allclose(out_st1, out_e, rtol=1e-6, atol=1e-6)
+    assert float((g_st - g2_e).abs().max()) <= 1e-6 * float(g2_e.abs().max())
+    assert isinstance(hip.load().cradle_last_error(), bytes)

@@ -84,3 +84,40 @@ def test_strided_views_and_rowbias():
     y = ops.gemm(ops.NT, z, Wd[:, : 2 * L], rowbias=wq, rowbias_mode=1, rowbias_n=N, rowscale=live)
     ref = z.double() @ Wd[:, : 2 * L].double().T + live.double().repeat(P).unsqueeze(1) * wq.double().repeat_interleave(N, 0)
     _close(y, ref, 2 * L)
+
+
+CONFIGS = [(2, 2, 16, 2, 1), (1, 1, 16, 2, 1), (1, 1, 16, 4, 1), (1, 1, 32, 2, 1), (1, 1, 32, 2, 2), (1, 1, 32, 4, 2),
+           (1, 2, 32, 2, 2), (2, 2, 32, 2, 2), (1, 1, 32, 2, 4), (1, 1, 32, 4, 4), (1, 1, 64, 2, 4), (1, 2, 32, 2, 4),
+           (2, 2, 32, 2, 4)]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_every_kernel_configuration_all_layouts(cfg):
+    """Each instantiated tile / K-step / wave arrangement (incl. the single-wave-tile kernels with a
+    four-way K split inside the workgroup), forced through the tuning hook, ragged sizes, with split-K."""
+    from cradle_vae_amd import hip, ops
+
+    lib = hip.load()
+    g = torch.Generator().manual_seed(3)
+    try:
+        for layout, (M, N, K) in [(ops.NT, (203, 140, 333)), (ops.NN, (203, 140, 332)), (ops.TN, (204, 140, 333)),
+                                  (ops.NT, (5, 400, 400)), (ops.TN, (400, 200, 1050))]:
+            for sk in (1, 3):
+                if layout == ops.NT:
+                    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+                    ref = A.double() @ B.double().T
+                elif layout == ops.NN:
+                    A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+                    ref = A.double() @ B.double()
+                else:
+                    A, B = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+                    ref = A.double().T @ B.double()
+                bias = torch.randn(N, generator=g)
+                ref = ref + bias.double()
+                ws = torch.empty(lib.cradle_gemm_workspace_floats(layout, M, N, K, 0), device=DEV)
+                lib.cradle_gemm_tune(*cfg, sk)
+                out = ops.gemm(layout, A.to(DEV), B.to(DEV), bias=bias.to(DEV), workspace=ws)
+                err = float((out.double().cpu() - ref).abs().max())
+                assert err <= 2e-7 * (K ** 0.5) * float(ref.abs().max()) + 1e-6, (cfg, layout, sk, err)
+    finally:
+        lib.cradle_gemm_tune(-1, -1, -1, -1, -1, -1)

@@ -31,9 +31,14 @@ shapes = [
     (ops.TN, 400, 400, 7680, "enc heads wgrad"), (ops.NT, 1050, 400, 400, "emb fwd"),
     (ops.NN, 1050, 400, 400, "emb dgrad"), (ops.TN, 400, 400, 1050, "emb wgrad"),
     (ops.NT, 2560, 400, 200, "offW fwd"), (ops.NN, 5120, 200, 400, "offW dgrad"), (ops.TN, 400, 200, 2560, "offW wgrad"),
-    (ops.NT, 1, 400, 400, "qc enc"),
+    (ops.NT, 1, 400, 400, "qc enc"), (ops.NN, 5, 400, 400, "qc dgrad"), (ops.TN, 400, 400, 5, "qc wgrad"),
+    (ops.NT, 1050, 400, 200, "emb l0 fwd"), (ops.NN, 1050, 200, 400, "emb dmask"), (ops.TN, 400, 200, 1050, "emb l0 wgrad"),
+    (ops.NT, 5, 400, 200, "wq fwd"),
 ]
-cfgs = [(2, 2, 16, 2, 1), (1, 1, 16, 2, 1), (1, 1, 16, 4, 1), (1, 1, 32, 2, 1), (1, 1, 32, 2, 2), (1, 1, 32, 4, 2), (1, 2, 32, 2, 2), (2, 2, 32, 2, 2)]
+if len(sys.argv) > 1:
+    shapes = [s for s in shapes if any(a in s[4] for a in sys.argv[1:])]
+cfgs = [(2, 2, 16, 2, 1), (1, 1, 16, 2, 1), (1, 1, 16, 4, 1), (1, 1, 32, 2, 1), (1, 1, 32, 2, 2), (1, 1, 32, 4, 2), (1, 2, 32, 2, 2), (2, 2, 32, 2, 2),
+        (1, 1, 32, 2, 4), (1, 1, 32, 4, 4), (1, 1, 64, 2, 4), (1, 2, 32, 2, 4), (2, 2, 32, 2, 4)]
 splits = [1, 2, 4, 8, 16]
 for layout, M, N, K, what in shapes:
     if layout == ops.NT:
