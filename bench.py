@@ -232,7 +232,7 @@ def main():
                 "unit": "TFLOP/s", "frac": gf / (elapsed / args.steps) / 1e12 / MFMA_F32_PEAK_TF,
                 "note": "minimal-form MLP GEMM flops (SURVEY 8d) / whole step time; fp32 v_mfma_f32_32x32x2_f32"}
         out = {
-            "metric": "cells/sec ELBO fwd+bwd (Norman shape)",
+            "metric": f"cells/sec ELBO fwd+bwd ({shape.name.capitalize()} shape)",
             "value": cells_per_s,
             "unit": "cells/s",
             "n_gpus": world,

@@ -29,6 +29,8 @@ _ALIASES = {
     "cradle_vae.analysis": "cradle_vae_amd.analysis",
     "cradle_vae.analysis.average_treatment_effects": "cradle_vae_amd.analysis.average_treatment_effects",
     "cradle_vae.data.utils.perturbation_dataset": "cradle_vae_amd.data",
+    "cradle_vae.data.utils.batch_statistics": "cradle_vae_amd.data",
+    "cradle_vae.data.utils.anndata": "cradle_vae_amd.analysis.metrics",
 }
 
 for _alias, _target in _ALIASES.items():
@@ -46,6 +48,8 @@ _datamodule.ObservationNormalizationStatistics = importlib.import_module(
     "cradle_vae_amd.guide").ObservationNormalizationStatistics
 _data_utils.perturbation_dataset = sys.modules["cradle_vae.data.utils.perturbation_dataset"]
 _data_utils.perturbation_datamodule = _datamodule
+_data_utils.batch_statistics = sys.modules["cradle_vae.data.utils.batch_statistics"]
+_data_utils.anndata = sys.modules["cradle_vae.data.utils.anndata"]
 _data.utils = _data_utils
 sys.modules["cradle_vae.data"] = _data
 sys.modules["cradle_vae.data.utils"] = _data_utils

@@ -102,3 +102,224 @@ class DeviceBatchLoader:
             yield batch
         if self.shuffle:
             self.epoch += 1
+
+
+def batch_log_mean(X: torch.Tensor, step_size: int = 1 << 16) -> torch.Tensor:
+    """mean over cells of log(X + 1) per gene (cradle_vae/data/utils/batch_statistics.py:4-10), in row
+    slabs so that a data set resident in HBM needs no second copy."""
+    total = torch.zeros(X.shape[1], device=X.device, dtype=torch.float32)
+    for i in range(0, X.shape[0], step_size):
+        total += torch.log(X[i:i + step_size].float() + 1).sum(0)
+    return total / X.shape[0]
+
+
+def batch_log_std(X: torch.Tensor, log_mean: torch.Tensor, correction: int = 1, step_size: int = 1 << 16) -> torch.Tensor:
+    """std over cells of log(X + 1) per gene around ``log_mean`` (batch_statistics.py:13-23)."""
+    total = torch.zeros(X.shape[1], device=X.device, dtype=torch.float32)
+    for i in range(0, X.shape[0], step_size):
+        total += ((torch.log(X[i:i + step_size].float() + 1) - log_mean) ** 2).sum(0)
+    return torch.sqrt(total / (X.shape[0] - correction))
+
+
+# ---------------------------------------------------------------------------------------------
+# Counterfactual inputs and an in-memory data module
+# ---------------------------------------------------------------------------------------------
+def build_counterfactual_inputs(X: torch.Tensor, treatment_codes: torch.Tensor, qc_fail: torch.Tensor,
+                                n_peers: int = 50, generator: Optional[torch.Generator] = None,
+                                peer_index: Optional[Dict[int, torch.Tensor]] = None,
+                                max_rows_per_gather: int = 1 << 22) -> torch.Tensor:
+    """cfX of one split (reference ``_get_cfX``, cradle_vae/data/norman/data_module.py:175-191): for every
+    cell, the per-gene (lower) median over ``min(n_peers, #fail)`` QC-failing cells of the same treatment,
+    drawn with replacement; zeros when the treatment has no QC-failing cell.  Runs on X's device, one
+    gather + median per treatment instead of a pandas ``apply`` over cells.
+
+    ``peer_index`` ({treatment code: (n_cells_of_t, k) positions into that treatment's fail list}) injects
+    the draws (tests); otherwise they come from ``generator``.
+    """
+    dev = X.device
+    n, G = X.shape
+    cfX = torch.zeros((n, G), device=dev, dtype=X.dtype)
+    codes = treatment_codes.to(dev)
+    fail = qc_fail.to(dev).bool()
+    for t in torch.unique(codes).tolist():
+        members = torch.nonzero(codes == t).squeeze(1)
+        fails = torch.nonzero((codes == t) & fail).squeeze(1)
+        if fails.numel() == 0:
+            continue
+        k = min(n_peers, fails.numel())
+        if peer_index is not None:
+            pos = peer_index[t].to(dev)
+        else:
+            pos = torch.randint(0, fails.numel(), (members.numel(), k), device=dev, generator=generator)
+        rows_per = max(1, max_rows_per_gather // (k * G))
+        for s in range(0, members.numel(), rows_per):
+            sel = fails[pos[s:s + rows_per]]  # (m, k) global row indices
+            cfX[members[s:s + rows_per]] = X[sel].median(dim=1)[0]
+    return cfX
+
+
+class TensorPerturbationDataModule:
+    """In-memory data module with the interface the training / evaluation code uses
+    (cradle_vae/data/utils/perturbation_datamodule.py:18-158; concrete behaviour as
+    norman/data_module.py:120-286): splits, obs counts, cfX, train-set statistics, unique-intervention
+    table and dosage map, data-side ATE.  Everything stays on ``device``."""
+
+    control_label = "non-targeting"
+
+    def __init__(self, X: torch.Tensor, D: torch.Tensor, qc: torch.Tensor, treatments: Iterable[str], splits: Iterable[str],
+                 x_var_names: Optional[Iterable[str]] = None, d_var_names: Optional[Iterable[str]] = None,
+                 qc_var_names: Optional[Iterable[str]] = None, batch_size: int = 512, device=None, seed: int = 0,
+                 control_label: Optional[str] = None, rank: int = 0, world_size: int = 1):
+        import pandas as pd
+
+        self.device = torch.device(device) if device is not None else X.device
+        self.batch_size, self.seed, self.rank, self.world_size = batch_size, seed, rank, world_size
+        if control_label is not None:
+            self.control_label = control_label
+        f32 = dict(device=self.device, dtype=torch.float32)
+        self.X, self.D, self.qc = X.to(**f32), D.to(**f32), qc.to(**f32)
+        n = self.X.shape[0]
+        self.obs = pd.DataFrame({"treatment": np.asarray(list(treatments)), "split": np.asarray(list(splits))},
+                                index=[f"cell{i}" for i in range(n)])
+        self.obs["total_qc"] = (self.qc.max(dim=1)[0] != 0).cpu().numpy().astype(int)
+        self.x_var_info = pd.DataFrame(index=list(x_var_names) if x_var_names is not None else [f"gene{i}" for i in range(self.X.shape[1])])
+        self.d_var_info = pd.DataFrame(index=list(d_var_names) if d_var_names is not None else [f"guide{i}" for i in range(self.D.shape[1])])
+        self.qc_var_info = pd.DataFrame(index=list(qc_var_names) if qc_var_names is not None else [f"qc{i}" for i in range(self.qc.shape[1])])
+        self.n_qc_fail = int(self.obs["total_qc"].sum())
+        self.n_qc_pass = n - self.n_qc_fail
+        codes = torch.from_numpy(pd.Categorical(self.obs["treatment"]).codes.astype(np.int64))
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        ids = np.asarray(self.obs.index)
+        self.datasets = {}
+        for split in ("train", "val", "test"):
+            idx = torch.from_numpy(np.nonzero((self.obs["split"] == split).to_numpy())[0])
+            di = idx.to(self.device)
+            Xs = self.X[di]
+            cfX = build_counterfactual_inputs(Xs, codes[idx], self.qc[di].max(dim=1)[0] != 0, generator=gen)
+            self.datasets[split] = SCRNASeqTensorPerturbationDataset(Xs, self.D[di], self.qc[di], cfX, ids=ids[idx.numpy()])
+        Xtr = self.datasets["train"].X
+        log_mean = batch_log_mean(Xtr)
+        self.x_train_statistics = _stats_cls()(
+            x_mean=Xtr.mean(0), x_std=Xtr.std(0), log_x_mean=log_mean, log_x_std=batch_log_std(Xtr, log_mean))
+        df = self.obs.groupby("treatment")["split"].agg(set).reset_index()
+        for split in ("train", "val", "test"):
+            df[split] = df["split"].apply(lambda s, split=split: split in s)
+        self.unique_observed_intervention_df = df.set_index("treatment").drop(columns=["split"])
+        first = self.obs.assign(i=np.arange(n)).drop_duplicates("treatment").set_index("treatment")["i"].to_dict()
+        self.unique_intervention_dosage_map = {k: self.D[v].cpu() for k, v in first.items()}
+
+    # ---- loaders
+    def _loader(self, split, shuffle):
+        return DeviceBatchLoader(self.datasets[split], self.batch_size, shuffle=shuffle, drop_last=shuffle, seed=self.seed,
+                                 rank=self.rank, world_size=self.world_size, device=self.device)
+
+    def train_dataloader(self):
+        return self._loader("train", True)
+
+    def val_dataloader(self):
+        return self._loader("val", False)
+
+    def test_dataloader(self):
+        return self._loader("test", False)
+
+    # ---- counts / info (perturbation_datamodule.py:19-135)
+    def get_train_perturbation_obs_counts(self):
+        return self.datasets["train"].get_dosage_obs_per_dim()
+
+    def get_val_perturbation_obs_counts(self):
+        return self.datasets["val"].get_dosage_obs_per_dim()
+
+    def get_test_perturbation_obs_counts(self):
+        return self.datasets["test"].get_dosage_obs_per_dim()
+
+    def get_train_qc_obs_counts(self):
+        return self.datasets["train"].get_qc_obs_per_dim()
+
+    def get_val_qc_obs_counts(self):
+        return self.datasets["val"].get_qc_obs_per_dim()
+
+    def get_test_qc_obs_counts(self):
+        return self.datasets["test"].get_qc_obs_per_dim()
+
+    def get_x_var_info(self):
+        return self.x_var_info.copy()
+
+    def get_d_var_info(self):
+        return self.d_var_info.copy()
+
+    def get_qc_var_info(self):
+        return self.qc_var_info.copy()
+
+    def get_qc_n(self):
+        return {"n_qc_pass": self.n_qc_pass, "n_qc_fail": self.n_qc_fail}
+
+    def get_obs_info(self):
+        return self.obs.copy()
+
+    def get_x_train_statistics(self):
+        return self.x_train_statistics
+
+    def get_unique_observed_intervention_info(self):
+        return self.unique_observed_intervention_df.copy()
+
+    def get_unique_observed_intervention_dosages(self, pert_names) -> torch.Tensor:
+        D = torch.zeros((len(pert_names), self.d_var_info.shape[0]))
+        for i, name in enumerate(pert_names):
+            D[i] = self.unique_intervention_dosage_map[name]
+        return D
+
+    def get_estimated_average_treatment_effects(self, method, split: Optional[str] = None, qc_pass: bool = False):
+        from .analysis.average_treatment_effects import estimate_data_average_treatment_effects
+        from .predictor import make_anndata
+
+        keep = np.ones(len(self.obs), dtype=bool)
+        if qc_pass:
+            keep &= (self.obs["total_qc"] == 0).to_numpy()
+        if split is not None:
+            keep &= (self.obs["split"] == split).to_numpy()
+        adata = make_anndata(self.X.cpu().numpy()[keep], obs=self.obs[keep], var=self.x_var_info.copy())
+        return estimate_data_average_treatment_effects(adata, label_col="treatment", control_label=self.control_label,
+                                                       method=method)
+
+    def get_simulated_latent_effects(self):
+        return None
+
+
+def _stats_cls():
+    from .guide import ObservationNormalizationStatistics
+
+    return ObservationNormalizationStatistics
+
+
+class SyntheticPerturbationDataModule(TensorPerturbationDataModule):
+    """Synthetic Perturb-seq-like data of a given shape (no data set can be fetched here): a low-rank
+    ground-truth effect per guide on top of gene base rates, Poisson counts, ~20 % QC-failing cells with
+    damped counts, control + single + (optionally) double perturbations, 80/10/10 split by cell."""
+
+    def __init__(self, n_cells: int = 4096, n_genes: int = 200, n_guides: int = 10, frac_combinations: float = 0.2,
+                 batch_size: int = 256, device=None, seed: int = 0, n_qc_pass: int = 0, n_qc_fail: int = 0, **kw):
+        g = torch.Generator().manual_seed(seed)
+        base = torch.exp(-1.0 + 1.2 * torch.randn(n_genes, generator=g))
+        base = base * (1e4 * n_genes / 5000) / base.sum() * 1.0
+        effect = 0.6 * torch.randn(n_guides, 4, generator=g) @ torch.randn(4, n_genes, generator=g) / 2.0
+        kind = torch.rand(n_cells, generator=g)
+        D = torch.zeros(n_cells, n_guides)
+        a = torch.randint(0, n_guides, (n_cells,), generator=g)
+        b = torch.randint(0, n_guides, (n_cells,), generator=g)
+        single = kind >= 0.15
+        D[single, a[single]] = 1.0
+        double = (kind >= 1.0 - frac_combinations) & (a != b)
+        D[double, b[double]] = 1.0
+        names = []
+        for i in range(n_cells):
+            nz = torch.nonzero(D[i]).squeeze(1).tolist()
+            names.append(self.control_label if not nz else "+".join(f"guide{j}" for j in nz))
+        qc = (torch.rand(n_cells, 1, generator=g) < 0.2).float()
+        lib = torch.exp(0.3 * torch.randn(n_cells, 1, generator=g))
+        rate = base * torch.exp(D @ effect) * lib * (1.0 - 0.5 * qc)
+        X = torch.poisson(rate, generator=g)
+        X[:, 0] += 1
+        u = torch.rand(n_cells, generator=g)
+        splits = np.where(u.numpy() < 0.8, "train", np.where(u.numpy() < 0.9, "val", "test"))
+        super().__init__(X, D, qc, names, splits, batch_size=batch_size, device=device, seed=seed, **kw)
+        self.true_effect = effect

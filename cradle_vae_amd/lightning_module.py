@@ -209,6 +209,11 @@ class TrainConfigPerturbationLightningModule(PerturbationLightningModule):
         build; register a namespace that provides them."""
         ns = type(self).data_namespace
         if ns is None:
+            from . import data as own
+
+            if hasattr(own, self.config["data_module"]):  # in-memory / synthetic data modules of this build
+                ns = own
+        if ns is None:
             raise NotImplementedError(
                 "no data-module namespace registered: set TrainConfigPerturbationLightningModule.data_namespace to an "
                 "object exposing the data-module classes named in config['data_module'] (e.g. the reference's "

@@ -40,6 +40,15 @@ class AnnDataLite:
     def shape(self):
         return self.X.shape
 
+    def __len__(self):
+        return self.X.shape[0]
+
+    def __getitem__(self, idx):
+        """Row selection by boolean mask or integer positions (``adata[mask]``, eval.py:115)."""
+        idx = np.asarray(idx)
+        obs = self.obs[idx] if idx.dtype == bool else self.obs.iloc[idx]
+        return AnnDataLite(X=self.X[idx], obs=obs, var=self.var, uns=self.uns)
+
     @property
     def obs_names(self):
         return self.obs.index

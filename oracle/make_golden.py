@@ -201,9 +201,67 @@ def ate_iwelbo_case(name, shape, seed, n_alt=4, ate_particles=12, ate_chunk=8, i
     print(f"{path}: ({os.path.getsize(path)} B)")
 
 
+def metrics_case(seed=21, n_cells=240, n_genes=64, n_pert=6):
+    """Reference analysis helpers on synthetic arrays: data-side ATE (both methods), the eval.py metric
+    stage (get_ate_metrics / jaccard_sim), align_adatas, and the train-set log statistics."""
+    import importlib.util
+
+    import pandas as pd
+
+    ref = rh.load_reference()
+    import anndata  # the harness stub
+    from cradle_vae.analysis.average_treatment_effects import estimate_data_average_treatment_effects
+    from cradle_vae.data.utils.anndata import align_adatas
+    from cradle_vae.data.utils.batch_statistics import batch_log_mean, batch_log_std
+
+    cwd = os.getcwd()
+    spec = importlib.util.spec_from_file_location("_ref_eval", os.path.join(rh.REFERENCE_ROOT, "eval.py"))
+    ref_eval = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_eval)  # chdirs into the reference
+    os.chdir(cwd)
+
+    rng = np.random.default_rng(seed)
+    lam = np.exp(rng.normal(0.5, 1.0, size=n_genes))
+    labels = np.array(["ctrl"] + [f"g{i}" for i in range(n_pert)])[rng.integers(0, n_pert + 1, size=n_cells)]
+    shift = np.exp(rng.normal(0, 0.4, size=(n_pert + 1, n_genes)))
+    shift[0] = 1.0
+    lab_idx = np.array([0 if l == "ctrl" else int(l[1:]) + 1 for l in labels])
+    X = rng.poisson(lam * shift[lab_idx]).astype(np.float32)
+    X[:, 0] += 1  # no empty cell
+    adata = anndata.AnnData(X=X, obs=pd.DataFrame({"pert": labels}, index=[f"c{i}" for i in range(n_cells)]),
+                            var=pd.DataFrame(index=[f"gene{i}" for i in range(n_genes)]))
+    out = {"X": X, "labels": labels.astype("U8")}
+    ates = {}
+    for method in ("mean", "perturbseq"):
+        res = estimate_data_average_treatment_effects(adata, "pert", "ctrl", method)
+        ates[method] = res
+        out[f"data_ate/{method}"] = np.asarray(res.X)
+        out[f"data_ate/{method}_index"] = np.array(list(res.obs.index)).astype("U8")
+    data_ate = ates["perturbseq"]
+    model_X = np.asarray(data_ate.X) + rng.normal(0, 0.15, size=data_ate.X.shape)
+    order = rng.permutation(model_X.shape[0])[:-1]  # the model side misses one perturbation, other order
+    model_ate = anndata.AnnData(X=model_X[order].astype(np.float32),
+                                obs=pd.DataFrame(index=np.array(list(data_ate.obs.index))[order]))
+    a, b = align_adatas(data_ate, model_ate)
+    out["model_ate/X"], out["model_ate/index"] = np.asarray(model_ate.X), np.array(list(model_ate.obs.index)).astype("U8")
+    out["aligned/index"] = np.array(list(a.obs.index)).astype("U8")
+    out["aligned/data_X"], out["aligned/model_X"] = np.asarray(a.X), np.asarray(b.X)
+    for k, v in ref_eval.get_ate_metrics(a, b).items():
+        out[f"metrics/{k}"] = np.float64(v)
+    Xt = torch.from_numpy(X)
+    lm = batch_log_mean(Xt, step_size=100)
+    out["stats/log_mean"], out["stats/log_std"] = lm.numpy(), batch_log_std(Xt, lm, step_size=100).numpy()
+    path = os.path.join(GOLDEN, "metrics_tiny.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: ({os.path.getsize(path)} B)", {k: float(v) for k, v in out.items() if k.startswith("metrics/")})
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     rh._GammaPoisson.SAMPLE_MODE = "mean"
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":  # only the analysis-helper fixture
+        metrics_case()
+        return
     T = syn.TINY
     elbo_case("tiny", T, 1)
     elbo_case("mid", syn.MID, 2)
@@ -240,6 +298,7 @@ def main():
     elbo_case("tiny_alpha", T, 7, alpha=0.3, beta=2.0)
     elbo_case("tiny_q2", dataclasses.replace(T, n_qc=2), 8)  # use_each_qc-style multi-column qc
     ate_iwelbo_case("tiny", T, 9)
+    metrics_case()
 
 
 if __name__ == "__main__":

@@ -114,8 +114,25 @@ def _install_stubs():
     mod("pyro", distributions=dist, _cradle_stub=True)
 
     class _AnnData:
+        """Just enough of anndata.AnnData for the reference's analysis helpers: X / obs / var / uns,
+        len(), .shape and row selection by boolean mask or integer positions."""
+
         def __init__(self, X=None, obs=None, var=None, uns=None):
             self.X, self.obs, self.var, self.uns = X, obs, var, ({} if uns is None else uns)
+
+        def __len__(self):
+            return self.X.shape[0]
+
+        @property
+        def shape(self):
+            return self.X.shape
+
+        def __getitem__(self, idx):
+            import numpy as np
+
+            idx = np.asarray(idx)
+            obs = self.obs[idx] if idx.dtype == bool else self.obs.iloc[idx]
+            return _AnnData(X=self.X[idx], obs=obs, var=self.var, uns=dict(self.uns))
 
     mod("anndata", AnnData=_AnnData)
     types_mod = mod("pytorch_lightning.utilities.types", STEP_OUTPUT=object)

@@ -169,3 +169,52 @@ def test_compat_alias_package_resolves_reference_import_paths():
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "compat"), root]))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_counterfactual_builder_matches_per_cell_loop():
+    """build_counterfactual_inputs against the reference's per-cell procedure (norman/data_module.py:
+    175-191) with the peer draws injected."""
+    from cradle_vae_amd.data import build_counterfactual_inputs
+
+    g = torch.Generator().manual_seed(1)
+    n, G = 90, 7
+    X = torch.poisson(4 * torch.rand(n, G, generator=g))
+    codes = torch.randint(0, 4, (n,), generator=g)
+    fail = torch.rand(n, generator=g) < 0.3
+    fail[codes == 3] = False  # a treatment without QC-failing cells -> zeros
+    peers = {}
+    for t in range(4):
+        n_t, n_f = int((codes == t).sum()), int(((codes == t) & fail).sum())
+        if n_f:
+            peers[t] = torch.randint(0, n_f, (n_t, min(50, n_f)), generator=g)
+    got = build_counterfactual_inputs(X, codes, fail, peer_index=peers, max_rows_per_gather=64)
+    want = torch.zeros(n, G)
+    for t in range(4):
+        members = torch.nonzero(codes == t).squeeze(1)
+        fails = torch.nonzero((codes == t) & fail).squeeze(1)
+        for j, i in enumerate(members.tolist()):
+            if len(fails):
+                want[i] = X[fails[peers[t][j]]].median(0)[0]
+    assert torch.equal(got, want) and float(got[codes == 3].abs().sum()) == 0.0
+
+
+def test_synthetic_data_module_interface():
+    from cradle_vae_amd.data import SyntheticPerturbationDataModule
+
+    dm = SyntheticPerturbationDataModule(n_cells=500, n_genes=24, n_guides=4, batch_size=50, seed=3)
+    n_tr = len(dm.datasets["train"])
+    assert n_tr + len(dm.datasets["val"]) + len(dm.datasets["test"]) == 500
+    assert torch.equal(dm.get_train_perturbation_obs_counts(), (dm.datasets["train"].D != 0).sum(0))
+    assert dm.get_qc_n()["n_qc_pass"] + dm.get_qc_n()["n_qc_fail"] == 500
+    stats = dm.get_x_train_statistics()
+    assert stats.log_x_mean.shape == (24,) and bool((stats.log_x_std > 0).all())
+    info = dm.get_unique_observed_intervention_info()
+    assert "non-targeting" in info.index and set(info.columns) == {"train", "val", "test"}
+    names = [x for x in info.index if x != "non-targeting"]
+    Dq = dm.get_unique_observed_intervention_dosages(names)
+    for name, row in zip(names, Dq):
+        assert sorted(f"guide{j}" for j in torch.nonzero(row).squeeze(1).tolist()) == sorted(name.split("+"))
+    ate = dm.get_estimated_average_treatment_effects("mean")
+    assert ate.X.shape == (len(names), 24) and ate.uns["control"] == "non-targeting"
+    b = next(iter(dm.train_dataloader()))
+    assert set(b) == {"X", "D", "qc", "cfX", "library_size", "idx"} and b["X"].shape == (50, 24)

@@ -69,3 +69,45 @@ def test_fit_reduces_loss_and_checkpoint_roundtrip(tmp_path):
     assert torch.equal(a, c)
     # the reloaded predictor shares the reloaded weights
     assert again.predictor.model is again.loss_module.model
+
+
+def test_end_to_end_synthetic_train_checkpoint_evaluate(tmp_path):
+    """train_*.py + eval.py flow on the synthetic data module: fit, checkpoint, reload, evaluate."""
+    from cradle_vae_amd.data import SyntheticPerturbationDataModule
+    from cradle_vae_amd.evaluate import evaluate_checkpoint
+    from cradle_vae_amd.lightning_module import TrainConfigPerturbationLightningModule, save_checkpoint
+    from cradle_vae_amd.trainer import fit
+
+    G, T = 64, 6
+    dm_kwargs = dict(n_cells=3000, n_genes=G, n_guides=T, batch_size=128, seed=1)
+    dm = SyntheticPerturbationDataModule(device=DEV, **dm_kwargs)
+    common = dict(n_latent=8, n_treatments=T, n_phenos=G, n_qc=1)
+    config = dict(
+        model="cradle_vae_Model", guide="cradle_vae_CorrelatedNormalGuide", loss_module="cradle_vae_ELBOLossModule",
+        predictor="cradle_vae_Predictor", data_module="SyntheticPerturbationDataModule",
+        data_module_kwargs=dict(dm_kwargs, **dm.get_qc_n()),
+        lightning_module_kwargs=dict(lr=2e-3, n_particles=3), loss_module_kwargs=dict(beta=0.5),
+        model_kwargs=dict(mask_prior_prob=0.05, embedding_prior_scale=1.0, likelihood_key="library_nb",
+                          decoder_n_layers=1, decoder_n_hidden=32, sum_mode=False, **common),
+        guide_kwargs=dict(basal_encoder_n_layers=1, basal_encoder_n_hidden=32,
+                          basal_encoder_input_normalization="log_standardize", embedding_encoder_n_layers=2,
+                          embedding_encoder_n_hidden=32, x_normalization_stats=dm.get_x_train_statistics(), **common))
+    torch.manual_seed(0)
+    mod = TrainConfigPerturbationLightningModule(
+        config=config, D_obs_counts_train=dm.get_train_perturbation_obs_counts().float(),
+        D_obs_counts_val=dm.get_val_perturbation_obs_counts().float(),
+        D_obs_counts_test=dm.get_test_perturbation_obs_counts().float(),
+        qc_obs_counts_train=dm.get_train_qc_obs_counts().float(), qc_obs_counts_val=dm.get_val_qc_obs_counts().float(),
+        qc_obs_counts_test=dm.get_test_qc_obs_counts().float()).to(DEV)
+    hist = fit(mod, dm.train_dataloader(), dm.val_dataloader(), max_epochs=12)
+    assert hist[-1]["val/loss"] < hist[0]["val/loss"]
+    path = os.path.join(tmp_path, "e2e.ckpt")
+    save_checkpoint(mod, path)
+    metrics = evaluate_checkpoint(path, "perturbseq", batch_size=128, ate_n_particles=256, data_module=dm)
+    for k in ("test/IWELBO", "ATE_pearsonr-all", "ATE_r2-all", "ATE_pearsonr_top20-all", "jaccard_sim_top20-all",
+              "jaccard_sim_top50-all", "ATE_pearsonr-test"):
+        assert k in metrics and metrics[k] == metrics[k], k  # present and not NaN
+    assert metrics["ATE_n_particles"] == 256 and -1.0 <= metrics["ATE_pearsonr-all"] <= 1.0
+    # the data module rebuilt from the checkpoint's config is the same data
+    dm2 = type(mod).load_from_checkpoint(path).get_data_module()
+    assert torch.equal(dm2.datasets["test"].X.cpu(), dm.datasets["test"].X.cpu())
