@@ -175,6 +175,7 @@ def main():
         # with K1 launched between them.  Switched on before the warm-up so that the timed
         # region holds no graph capture.
         stepper.fused.k1_events = [] if rank == 0 else None
+        stepper.fused.gemm_events = [] if rank == 0 else None
 
     def one_step(i):
         return stepper(batch, n_particles=shape.n_particles)
@@ -188,6 +189,8 @@ def main():
     ops.KERNEL_TIMING = True
     if stepper.fused is not None and stepper.fused.k1_events is not None:
         stepper.fused.k1_events.clear()
+        if stepper.fused.gemm_events is not None:
+            stepper.fused.gemm_events.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -231,6 +234,14 @@ def main():
         mfma = {"flops_per_step": gf, "achieved": gf / (elapsed / args.steps) / 1e12, "peak": MFMA_F32_PEAK_TF,
                 "unit": "TFLOP/s", "frac": gf / (elapsed / args.steps) / 1e12 / MFMA_F32_PEAK_TF,
                 "note": "minimal-form MLP GEMM flops (SURVEY 8d) / whole step time; fp32 v_mfma_f32_32x32x2_f32"}
+        if stepper.fused is not None and stepper.fused.gemm_events:
+            # the largest GEMM alone (decoder output layer forward), HIP events around its launch
+            tg = [ev.elapsed_ms() * 1e-3 for ev in stepper.fused.gemm_events]
+            tg = sum(tg) / len(tg)
+            fl = 2.0 * P * N * G * shape.decoder_n_hidden
+            mfma["largest_gemm"] = {"kernel": "gemm_f32_kernel NT (decoder output layer fwd)", "M": P * N, "N": G,
+                                    "K": shape.decoder_n_hidden, "flops": fl, "launch_us": tg * 1e6,
+                                    "achieved": fl / tg / 1e12, "frac": fl / tg / 1e12 / MFMA_F32_PEAK_TF}
         out = {
             "metric": f"cells/sec ELBO fwd+bwd ({shape.name.capitalize()} shape)",
             "value": cells_per_s,

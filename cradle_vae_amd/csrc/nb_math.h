@@ -83,9 +83,19 @@ __device__ __forceinline__ float nb_main_term(float mu, float x, float c, float&
   const bool clamped = rate0 < kRateMin;  // torch.clamp(min=1e-6): gradient passes where rate0 >= min
   const float rate = clamped ? kRateMin : rate0;
   const float lr = fast_log(rate);
-  const float l1p = log1p_acc(rate);
+  float l1p;
+  float rmc = 0.f;
   if (BWD) {
-    const float rmc = fast_rcp(m + c);
+    // 1/(1+rate) = m/(m+c): the reciprocal the gradient needs anyway also serves the first-order
+    // correction of log1p (|d/u| <= 2^-24, so the clamped case may use the same value: rate is 1e-6)
+    rmc = fast_rcp(m + c);
+    const float u1 = 1.0f + rate;
+    const float d = rate - (u1 - 1.0f);
+    l1p = fast_log(u1) + d * (clamped ? 1.0f : m * rmc);
+  } else {
+    l1p = log1p_acc(rate);
+  }
+  if (BWD) {
     const float xm = x - m;
     u = clamped ? 0.f : mu * rate * xm * rmc;
     du = lr - l1p - (clamped ? 0.f : xm * rmc);

@@ -79,6 +79,10 @@ struct cradle_step_desc {
   // kernels (K1); NULL = off
   void* ev_k1_begin;
   void* ev_k1_end;
+  // optional profiling of the largest GEMM (decoder output layer forward, 2*P*N*G*Hd flop): events
+  // recorded on the stream right before / after its launch; NULL = off (ignored by the graphed entry)
+  void* ev_gemm_begin;
+  void* ev_gemm_end;
 };
 
 }  // extern "C"
@@ -478,7 +482,9 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
     c.gemm(GEMM_NT, p);
   }
   trunk_fwd(c, d.dec, PN, Hd, w.yd, w.rd);
+  if (d.ev_gemm_begin) (void)hipEventRecord((hipEvent_t)d.ev_gemm_begin, s);
   head_fwd(c, d.dec, PN, Hd, G, w.yd[d.dec.n_layers - 1], w.logits);
+  if (d.ev_gemm_end) (void)hipEventRecord((hipEvent_t)d.ev_gemm_end, s);
   if (c.rc) return c.rc;
   }  // PH_PRE
   if (phases & PH_K1) {
@@ -707,7 +713,9 @@ int cradle_elbo_step_graphed(const cradle_step_desc* dp, hipStream_t s, int* rec
   if (rc) return rc;
   const cradle_step_desc& d = *dp;
   cradle_step_desc key = d;
-  key.ev_k1_begin = key.ev_k1_end = nullptr;
+  key.ev_k1_begin = key.ev_k1_end = key.ev_gemm_begin = key.ev_gemm_end = nullptr;
+  cradle_step_desc dg = d;  // events around the GEMM cannot be captured with timing: dropped here
+  dg.ev_gemm_begin = dg.ev_gemm_end = nullptr;
   const bool split = d.ev_k1_begin || d.ev_k1_end;
   GraphSlot* sl = nullptr;
   for (auto& cand : gs.slot)
@@ -718,7 +726,7 @@ int cradle_elbo_step_graphed(const cradle_step_desc* dp, hipStream_t s, int* rec
     if (!sl) {  // cache full: launch this descriptor's kernels directly on the caller's stream
       GDBG("cache full: eager launch");
       c.st[0] = s;
-      return run_step(d, w, c, PH_ALL);
+      return run_step(dg, w, c, PH_ALL);
     }
     for (sl->nev = 0; sl->nev < kMaxEvents; ++sl->nev)
       if (hipEventCreateWithFlags(&sl->ev[sl->nev], hipEventDisableTiming) != hipSuccess) {
@@ -727,8 +735,8 @@ int cradle_elbo_step_graphed(const cradle_step_desc* dp, hipStream_t s, int* rec
         return CRADLE_ERR_HIP;
       }
     c.ev = sl->ev;
-    rc = capture(d, w, c, split ? PH_PRE : PH_ALL, gs.cs, &sl->graph[0], &sl->exec[0]);
-    if (!rc && split) rc = capture(d, w, c, PH_POST, gs.cs, &sl->graph[1], &sl->exec[1]);
+    rc = capture(dg, w, c, split ? PH_PRE : PH_ALL, gs.cs, &sl->graph[0], &sl->exec[0]);
+    if (!rc && split) rc = capture(dg, w, c, PH_POST, gs.cs, &sl->graph[1], &sl->exec[1]);
     if (rc) {
       abandon_slot(*sl);
       return rc;
@@ -745,7 +753,7 @@ int cradle_elbo_step_graphed(const cradle_step_desc* dp, hipStream_t s, int* rec
   ok = ok && hipGraphLaunch(sl->exec[0], gs.cs) == hipSuccess;
   GDBG("launched ok=%d", (int)ok);
   if (ok && split) {
-    rc = run_step(d, w, c, PH_K1);
+    rc = run_step(dg, w, c, PH_K1);
     if (rc) return rc;
     ok = hipGraphLaunch(sl->exec[1], gs.cs) == hipSuccess;
   }

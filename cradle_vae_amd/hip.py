@@ -91,7 +91,8 @@ class StepDesc(ctypes.Structure):
                                           "u_mask", "eps_E", "eps_qc_E", "eps_z")]
         + [("beta", ctypes.c_float), ("alpha", ctypes.c_float), ("compute_grads", i32)]
         + [("out", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
-           ("workspace_bytes", i64), ("ev_k1_begin", ctypes.c_void_p), ("ev_k1_end", ctypes.c_void_p)]
+           ("workspace_bytes", i64), ("ev_k1_begin", ctypes.c_void_p), ("ev_k1_end", ctypes.c_void_p),
+           ("ev_gemm_begin", ctypes.c_void_p), ("ev_gemm_end", ctypes.c_void_p)]
     )
 
 

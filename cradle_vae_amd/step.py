@@ -145,6 +145,7 @@ class FusedElboStep:
         self._shape_key = None
         self._states = {}
         self.k1_events = None  # list collecting hip.EventPair around K1 when profiling (bench.py)
+        self.gemm_events = None  # same around the decoder output-layer GEMM (the largest of the step)
         # Optional HIP-graph replay (cradle_elbo_step_graphed).  Off by default: on ROCm 7.2 / MI355X
         # the replay of this multi-branch graph measured slower (1.52 ms) than launching its kernels
         # on three streams (1.35 ms) -- the step is GPU-bound, not enqueue-bound.  The graph bakes every
@@ -274,6 +275,12 @@ class FusedElboStep:
             d.ev_k1_begin, d.ev_k1_end = ev.begin, ev.end
         else:
             d.ev_k1_begin, d.ev_k1_end = None, None
+        if self.gemm_events is not None and not self.use_graph:
+            ev = hip.EventPair()
+            self.gemm_events.append(ev)
+            d.ev_gemm_begin, d.ev_gemm_end = ev.begin, ev.end
+        else:
+            d.ev_gemm_begin, d.ev_gemm_end = None, None
         if self.use_graph:
             recaptured = ctypes.c_int(0)
             hip.check(self.lib.cradle_elbo_step_graphed(ctypes.byref(d), hip.stream(), ctypes.byref(recaptured)),

@@ -179,6 +179,8 @@ typedef struct cradle_step_desc {
   int64_t workspace_bytes;
   void* ev_k1_begin;      /* optional hipEvent_t recorded before / after the K1 launches; NULL = off */
   void* ev_k1_end;
+  void* ev_gemm_begin;    /* optional hipEvent_t recorded before / after the largest GEMM of the step (decoder */
+  void* ev_gemm_end;      /* output layer forward, 2*P*N*G*Hd flop); NULL = off; ignored by the graphed entry */
 } cradle_step_desc;
 
 int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only the sizes are read */
