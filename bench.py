@@ -133,6 +133,11 @@ def cpu_baseline(shape, seconds_budget=25.0):
     }
 
 
+def trace(msg):
+    if os.environ.get("CRADLE_BENCH_TRACE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +146,7 @@ def main():
     ap.add_argument("--shape", default="norman")
     ap.add_argument("--step-impl", default="auto", choices=["auto", "fused", "modular"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph instead of launching its kernels on three streams")
     args = ap.parse_args()
 
@@ -153,13 +159,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    dev_index = local_rank % max(1, torch.cuda.device_count())  # wraps only in a gloo rehearsal on fewer GPUs than ranks
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    trace("process group ready")
     hip.load()
 
     shape = syn.SHAPES[args.shape]
@@ -180,9 +191,12 @@ def main():
     def one_step(i):
         return stepper(batch, n_particles=shape.n_particles)
 
+    trace("modules built")
     for i in range(args.warmup):
         one_step(i)
+        trace(f"warmup step {i} enqueued")
     torch.cuda.synchronize()
+    trace("warmup done")
     if world > 1:
         dist.barrier()
     ops.KERNEL_TIMERS.clear()
@@ -199,10 +213,13 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    trace("timed region done")
     ops.KERNEL_TIMING = False
     if world > 1:
+        from cradle_vae_amd import parallel
+
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        parallel._all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     ms_per_step = elapsed / args.steps * 1e3
     cells_per_s = shape.n_cells * world / (elapsed / args.steps)

@@ -49,4 +49,13 @@ int cradle_event_elapsed_ms(void* begin, void* end, float* ms) {
   return CRADLE_OK;
 }
 
+// makes everything enqueued on `stream` from now on wait for `ev` (no-op if it was never recorded)
+int cradle_stream_wait_event(hipStream_t stream, void* ev) {
+  if (!ev || hipStreamWaitEvent(stream, (hipEvent_t)ev, 0) != hipSuccess) {
+    cradle_set_error("stream_wait_event failed");
+    return CRADLE_ERR_HIP;
+  }
+  return CRADLE_OK;
+}
+
 }  // extern "C"

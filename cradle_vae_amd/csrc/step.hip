@@ -83,6 +83,11 @@ struct cradle_step_desc {
   // recorded on the stream right before / after its launch; NULL = off (ignored by the graphed entry)
   void* ev_gemm_begin;
   void* ev_gemm_end;
+  // optional (data-parallel training): events that fire as soon as a bucket of gradients is final,
+  // so that the caller can start reducing it while the rest of the backward pass runs.
+  // [0]: decoder gradients (d_dec.*, d_log_concentration); [1]: basal-encoder gradients (d_enc.*).
+  // Everything else is final when the step's work on `stream` is.  NULL = off; ignored when graphed.
+  void* ev_bucket[2];
 };
 
 }  // extern "C"
@@ -230,6 +235,7 @@ constexpr int kMaxEvents = 160;
 struct StreamSet {
   bool ready = false;
   hipStream_t side[2];
+  hipStream_t marker;  // carries only event waits/records: "all three streams have reached this point"
   hipEvent_t ev[kMaxEvents];
 };
 StreamSet g_streams[16];
@@ -247,6 +253,10 @@ int get_streams(StreamSet** out) {
         cradle_set_error("elbo_step: side stream creation failed");
         return CRADLE_ERR_HIP;
       }
+    if (hipStreamCreateWithFlags(&ss.marker, hipStreamNonBlocking) != hipSuccess) {
+      cradle_set_error("elbo_step: marker stream creation failed");
+      return CRADLE_ERR_HIP;
+    }
     for (int i = 0; i < kMaxEvents; ++i)
       if (hipEventCreateWithFlags(&ss.ev[i], hipEventDisableTiming) != hipSuccess) {
         cradle_set_error("elbo_step: event creation failed");
@@ -259,6 +269,7 @@ int get_streams(StreamSet** out) {
 }
 
 struct Ctx {
+  hipStream_t marker = nullptr;
   hipStream_t st[3];  // 0 = the caller's stream (critical path), 1/2 = side streams
   float* splitk[3];
   hipEvent_t* ev;
@@ -285,6 +296,28 @@ struct Ctx {
     }
   }
 };
+
+// records `user_ev` at the point where all three streams have finished what they hold so far
+void mark_all(Ctx& c, void* user_ev) {
+  if (!user_ev || c.rc || !c.marker) return;
+  for (int q = 0; q < 3; ++q) {
+    if (c.nev >= kMaxEvents) {
+      cradle_set_error("elbo_step: out of fork/join events");
+      c.rc = CRADLE_ERR_HIP;
+      return;
+    }
+    hipEvent_t e = c.ev[c.nev++];
+    if (hipEventRecord(e, c.st[q]) != hipSuccess || hipStreamWaitEvent(c.marker, e, 0) != hipSuccess) {
+      cradle_set_error("elbo_step: event record/wait failed");
+      c.rc = CRADLE_ERR_HIP;
+      return;
+    }
+  }
+  if (hipEventRecord((hipEvent_t)user_ev, c.marker) != hipSuccess) {
+    cradle_set_error("elbo_step: bucket event record failed");
+    c.rc = CRADLE_ERR_HIP;
+  }
+}
 
 GemmParams gp(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K) {
   GemmParams p = {};
@@ -518,6 +551,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   STEP(weighted_rowgroup_sum(da0d, w.cp.live, P, N, Hd, w.dwq, s));
   c.after(2, 0);
   c.gemm(GEMM_TN, gp(w.dwq, Hd, w.qsum, L, d.d_dec.W[0] + 2 * L, 3 * L, Hd, L, P), 2);  // dW0[:, 2L:]
+  mark_all(c, d.ev_bucket[0]);  // every decoder gradient has been enqueued
   c.gemm(GEMM_NN, gp(w.dwq, Hd, Wd0 + 2 * L, 3 * L, w.dq_dec, L, P, L, Hd));            // d qsum
   c.gemm(GEMM_NN, gp(da0d, Hd, Wd0, 3 * L, w.dzoff, 2 * L, PN, 2 * L, Hd));             // [dz | doff]
   if (c.rc) return c.rc;
@@ -543,6 +577,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
     c.gemm(GEMM_TN, p, 2);
   }
   c.gemm(GEMM_TN, gp(w.dvq, He, w.qcE, L, dWenc0 + G + L, ldenc, He, L, PP * Q), 2);      // dWqc
+  mark_all(c, d.ev_bucket[1]);  // every basal-encoder gradient has been enqueued
   c.gemm(GEMM_NN, gp(w.doffW, He, Wenc0 + G, ldenc, w.doffenc, L, 2 * PN, L, He));        // d offsets via encoder
   c.gemm(GEMM_NN, gp(w.dvq, He, Wenc0 + G + L, ldenc, w.dq_enc, L, PP * Q, L, He));       // d qc_E via encoder
   if (c.rc) return c.rc;
@@ -595,6 +630,7 @@ int prepare(const cradle_step_desc* dp, Work& w, Ctx& c, hipStream_t main) {
   rc = get_streams(&ss);
   if (rc) return rc;
   c.st[0] = main; c.st[1] = ss->side[0]; c.st[2] = ss->side[1];
+  c.marker = ss->marker;
   for (int i = 0; i < 3; ++i) c.splitk[i] = w.splitk[i];
   c.ev = ss->ev;
   return CRADLE_OK;
@@ -713,9 +749,9 @@ int cradle_elbo_step_graphed(const cradle_step_desc* dp, hipStream_t s, int* rec
   if (rc) return rc;
   const cradle_step_desc& d = *dp;
   cradle_step_desc key = d;
-  key.ev_k1_begin = key.ev_k1_end = key.ev_gemm_begin = key.ev_gemm_end = nullptr;
+  key.ev_k1_begin = key.ev_k1_end = key.ev_gemm_begin = key.ev_gemm_end = key.ev_bucket[0] = key.ev_bucket[1] = nullptr;
   cradle_step_desc dg = d;  // events around the GEMM cannot be captured with timing: dropped here
-  dg.ev_gemm_begin = dg.ev_gemm_end = nullptr;
+  dg.ev_gemm_begin = dg.ev_gemm_end = dg.ev_bucket[0] = dg.ev_bucket[1] = nullptr;
   const bool split = d.ev_k1_begin || d.ev_k1_end;
   GraphSlot* sl = nullptr;
   for (auto& cand : gs.slot)

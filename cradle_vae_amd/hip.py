@@ -26,6 +26,7 @@ PROTOTYPES = {
     "cradle_event_create": (i32, [ctypes.POINTER(ctypes.c_void_p)]),
     "cradle_event_destroy": (i32, [ctypes.c_void_p]),
     "cradle_event_elapsed_ms": (i32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "cradle_stream_wait_event": (i32, [c_stream, ctypes.c_void_p]),
     "cradle_nb_gene_consts": (i32, [c_float_p, c_float_p, i32, c_stream]),
     "cradle_nb_logprob_fwd": (i32, [c_float_p, i64, c_float_p, i64, c_float_p, c_float_p, c_float_p, i32, i32, i32, c_stream]),
     "cradle_nb_logprob_fwd_bwd": (
@@ -92,7 +93,7 @@ class StepDesc(ctypes.Structure):
         + [("beta", ctypes.c_float), ("alpha", ctypes.c_float), ("compute_grads", i32)]
         + [("out", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
            ("workspace_bytes", i64), ("ev_k1_begin", ctypes.c_void_p), ("ev_k1_end", ctypes.c_void_p),
-           ("ev_gemm_begin", ctypes.c_void_p), ("ev_gemm_end", ctypes.c_void_p)]
+           ("ev_gemm_begin", ctypes.c_void_p), ("ev_gemm_end", ctypes.c_void_p), ("ev_bucket", ctypes.c_void_p * 2)]
     )
 
 

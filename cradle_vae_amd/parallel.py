@@ -45,8 +45,21 @@ def allreduce_sum_(flat: torch.Tensor, world_size: int) -> torch.Tensor:
     """In-place sum of ``flat`` over ranks (no-op for one rank).  The mean is taken by the
     consumer (``cradle_adam_step``'s grad_scale = 1/world_size) so that no extra pass is needed."""
     if world_size > 1:
-        torch.distributed.all_reduce(flat)
+        _all_reduce(flat)
     return flat
+
+
+def _all_reduce(t: torch.Tensor, op=None) -> None:
+    """RCCL reduces device tensors in place; with the gloo backend (rehearsals of the N>1 path on a
+    box with fewer GPUs than ranks, CPU tests) device tensors are staged through host memory."""
+    dist = torch.distributed
+    kw = {} if op is None else {"op": op}
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, **kw)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, **kw)
 
 
 def allreduce_mean_grads_(params: List[torch.nn.Parameter], world_size: int) -> None:
@@ -54,7 +67,7 @@ def allreduce_mean_grads_(params: List[torch.nn.Parameter], world_size: int) -> 
     if world_size == 1:
         return
     flat = torch.cat([p.grad.reshape(-1) for p in params])
-    torch.distributed.all_reduce(flat)
+    _all_reduce(flat)
     flat.div_(world_size)
     off = 0
     for p in params:

@@ -146,6 +146,9 @@ class FusedElboStep:
         self._states = {}
         self.k1_events = None  # list collecting hip.EventPair around K1 when profiling (bench.py)
         self.gemm_events = None  # same around the decoder output-layer GEMM (the largest of the step)
+        # hip.EventPair whose two events fire when the decoder / basal-encoder gradients are final
+        # (trainer.TrainStep starts their all-reduce while the rest of the backward pass runs)
+        self.bucket_events = None
         # Optional HIP-graph replay (cradle_elbo_step_graphed).  Off by default: on ROCm 7.2 / MI355X
         # the replay of this multi-branch graph measured slower (1.52 ms) than launching its kernels
         # on three streams (1.35 ms) -- the step is GPU-bound, not enqueue-bound.  The graph bakes every
@@ -275,6 +278,8 @@ class FusedElboStep:
             d.ev_k1_begin, d.ev_k1_end = ev.begin, ev.end
         else:
             d.ev_k1_begin, d.ev_k1_end = None, None
+        be = self.bucket_events if (compute_grads and not self.use_graph) else None
+        d.ev_bucket[0], d.ev_bucket[1] = (be.begin, be.end) if be is not None else (None, None)
         if self.gemm_events is not None and not self.use_graph:
             ev = hip.EventPair()
             self.gemm_events.append(ev)

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import torch
 
 from . import parallel
@@ -42,6 +44,12 @@ class TrainStep:
             self.exp_avg = torch.zeros_like(a.flat)
             self.exp_avg_sq = torch.zeros_like(a.flat)
             self.norm_ws = torch.zeros(hip.load().cradle_adam_workspace_floats(), device=self.device)
+            # N > 1: bucketed gradient all-reduce overlapped with the backward pass (CRADLE_OVERLAP_ALLREDUCE=0
+            # falls back to one all-reduce of the whole arena after the step)
+            self.overlap = world_size > 1 and os.environ.get("CRADLE_OVERLAP_ALLREDUCE", "1") != "0"
+            if self.overlap:
+                self.fused.bucket_events = hip.EventPair()
+                self.comm_stream = torch.cuda.Stream(device=self.device)
 
     def draw_noise(self, P, N):
         g = self.lm.guide
@@ -61,7 +69,10 @@ class TrainStep:
                 qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
                 n_particles=n_particles, gen_plated=self.gen_plated, gen_local=self.gen_local)
         a = f.arena
-        parallel.allreduce_sum_(a.grad, self.world_size)  # one RCCL call on the flat gradient arena; averaged inside Adam
+        if self.world_size > 1 and self.overlap and not f.use_graph:
+            self._bucketed_allreduce(a)
+        else:
+            parallel.allreduce_sum_(a.grad, self.world_size)  # one RCCL call on the flat gradient arena; averaged inside Adam
         self.step_count += 1
         hip.check(
             hip.load().cradle_adam_step(
@@ -72,6 +83,26 @@ class TrainStep:
             "cradle_adam_step")
         self.last_out = out
         return out[0]
+
+    def _bucketed_allreduce(self, a):
+        """Sum of the gradient arena over ranks in three contiguous buckets, in the order the backward
+        pass finishes them (decoder, basal encoder, the rest), on a communication stream that waits for
+        the events the step records: the first two all-reduces run under the remaining backward kernels."""
+        from . import hip
+
+        lib = hip.load()
+        ev = self.fused.bucket_events
+        o_enc, o_dec = a.offsets["enc.W0"], a.offsets["dec.W0"]
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(self.comm_stream):
+            cs = self.comm_stream.cuda_stream
+            hip.check(lib.cradle_stream_wait_event(cs, ev.begin), "stream_wait_event")
+            parallel._all_reduce(a.grad[o_dec:])
+            hip.check(lib.cradle_stream_wait_event(cs, ev.end), "stream_wait_event")
+            parallel._all_reduce(a.grad[o_enc:o_dec])
+            self.comm_stream.wait_stream(cur)  # q(M), q(E|M), q(qc_E): final when the step is
+            parallel._all_reduce(a.grad[:o_enc])
+        cur.wait_stream(self.comm_stream)
 
     def __call__(self, batch: Dict[str, torch.Tensor], n_particles: int) -> torch.Tensor:
         if self.fused is not None:

@@ -42,6 +42,8 @@ int cradle_device_count(void);
 int cradle_event_create(void** ev);
 int cradle_event_destroy(void* ev);
 int cradle_event_elapsed_ms(void* begin, void* end, float* ms);
+/* everything enqueued on `stream` from now on waits for `ev` (cradle_step_desc.ev_bucket consumers) */
+int cradle_stream_wait_event(cradle_stream_t stream, void* ev);
 
 /* ---- K1: Gamma-Poisson (negative binomial) log-likelihood over genes ----------------
  * Replaces, for one decoder variant (good or bad):
@@ -181,6 +183,10 @@ typedef struct cradle_step_desc {
   void* ev_k1_end;
   void* ev_gemm_begin;    /* optional hipEvent_t recorded before / after the largest GEMM of the step (decoder */
   void* ev_gemm_end;      /* output layer forward, 2*P*N*G*Hd flop); NULL = off; ignored by the graphed entry */
+  void* ev_bucket[2];     /* optional hipEvent_t fired as soon as a gradient bucket is final (replaces DDP's
+                             bucketed backward hooks under Lightning's ddp strategy, train_norman.py:89-97):
+                             [0] decoder gradients (d_dec.*, d_log_concentration), [1] basal-encoder gradients
+                             (d_enc.*); the rest is final with the step.  NULL = off; ignored when graphed */
 } cradle_step_desc;
 
 int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only the sizes are read */

@@ -1,0 +1,71 @@
+"""Two ranks on one GPU (gloo, device tensors staged through the host): the data-parallel training step
+with the bucketed all-reduce that overlaps the backward pass must give exactly the parameters of the
+single all-reduce after the step, identical on both ranks.  (RCCL itself needs >= 2 GPUs; the driver's
+scaling run covers it.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+WORLD = 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, port, overlap, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo",
+                      CRADLE_OVERLAP_ALLREDUCE="1" if overlap else "0")
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from cradle_vae_amd import synthetic as syn
+        from cradle_vae_amd.trainer import TrainStep
+        from tests import golden_io as gio
+        from tests.test_modular_gpu import build_loss_module
+
+        torch.cuda.set_device(0)
+        case = gio.load_elbo("mid", torch.float32, "cuda:0")
+        lm = build_loss_module(case)
+        st = TrainStep(lm, lr=1e-3, world_size=WORLD, seed=7)
+        assert st.fused is not None and st.overlap == overlap
+        shape = syn.MID
+        batch = syn.make_batch(shape, seed=50 + rank, device="cuda:0")  # each rank its own cells
+        losses = [float(st(batch, n_particles=shape.n_particles)) for _ in range(4)]
+        torch.cuda.synchronize()
+        out[rank] = (st.fused.arena.flat.detach().cpu().clone(), losses)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(overlap):
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, port, overlap, out)) for r in range(WORLD)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=150)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        assert sorted(out.keys()) == [0, 1], "a rank failed"
+        return {r: out[r] for r in range(WORLD)}
+
+
+def test_overlapped_bucket_allreduce_equals_single_allreduce():
+    a = _run(overlap=True)
+    b = _run(overlap=False)
+    assert torch.equal(a[0][0], a[1][0]), "ranks diverged with the bucketed all-reduce"
+    assert torch.equal(b[0][0], b[1][0]), "ranks diverged with the single all-reduce"
+    assert torch.equal(a[0][0], b[0][0]), "bucketed and single all-reduce disagree"
+    assert a[0][1] != a[1][1]  # different cells per rank: different local losses
