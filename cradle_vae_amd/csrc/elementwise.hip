@@ -599,7 +599,7 @@ int gather_offsets(const float* ME, const DosagePlan& plan, float* offA, int64_t
 }
 
 // dME[pp,t,:] = sum_{cells n of t} D[n,t] * (a1 + a2)[pp,n,:]   (pp < P)   or  b1[pp-P,n,:]  (pp >= P)
-__global__ __launch_bounds__(64) void scatter_offsets_kernel(const int* __restrict__ tstart, const int* __restrict__ csc_cell,
+__global__ __launch_bounds__(256) void scatter_offsets_kernel(const int* __restrict__ tstart, const int* __restrict__ csc_cell,
                                                              const float* __restrict__ csc_val, const float* __restrict__ a1,
                                                              int64_t ld1, const float* __restrict__ a2, int64_t ld2,
                                                              const float* __restrict__ b1, int64_t ldb1, float* __restrict__ dME,
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64) void scatter_offsets_kernel(const int* __restri
   const int t = blockIdx.x, pp = blockIdx.y;
   const int e0 = tstart[t], e1 = tstart[t + 1];
   float* out = dME + ((int64_t)pp * T + t) * L;
-  for (int l = threadIdx.x; l < L; l += 64) {
+  for (int l = threadIdx.x; l < L; l += blockDim.x) {
     float acc = 0.f;
     for (int e = e0; e < e1; ++e) {
       const int n = csc_cell[e];
@@ -622,7 +622,8 @@ __global__ __launch_bounds__(64) void scatter_offsets_kernel(const int* __restri
 
 int scatter_offsets(const DosagePlan& plan, const float* a1, int64_t ld1, const float* a2, int64_t ld2, const float* b1,
                     int64_t ldb1, float* dME, int PP, int P, int N, int T, int L, hipStream_t stream) {
-  hipLaunchKernelGGL(scatter_offsets_kernel, dim3(T, PP), dim3(64), 0, stream, plan.tstart, plan.csc_cell, plan.csc_val, a1,
+  const int nt = L <= 64 ? 64 : (L <= 128 ? 128 : 256);  // one pass over the latent columns
+  hipLaunchKernelGGL(scatter_offsets_kernel, dim3(T, PP), dim3(nt), 0, stream, plan.tstart, plan.csc_cell, plan.csc_val, a1,
                      ld1, a2, ld2, b1, ldb1, dME, P, N, T, L);
   CRADLE_CHECK_LAUNCH("scatter_offsets_kernel");
   return CRADLE_OK;
@@ -684,16 +685,17 @@ __global__ __launch_bounds__(128) void enc_combine_bwd_kernel(const float* __res
   }
 }
 
-// dvq[pp,q,:] = sum_n s_q[n] dpre[variant rows]; 64 columns x 16 cell slices per block
+// dvq[pp,q,:] = sum_n s_q[n] dpre[variant rows]; 16 columns x 64 cell slices per block
 __global__ __launch_bounds__(1024) void enc_combine_bwd_vq_kernel(const float* __restrict__ dpre, const float* __restrict__ qc,
                                                                   float* __restrict__ dvq, int P, int N, int Q, int H) {
-  __shared__ float part[16][64];
+  __shared__ float part[64][17];
   const int q = blockIdx.y % Q, pp = blockIdx.y / Q;
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + c;
   const int64_t PN = (int64_t)P * N;
   float acc = 0.f;
   if (j < H) {
-    for (int n = sl; n < N; n += 16) {
+    for (int n = sl; n < N; n += 64) {
       const float s = qc[(int64_t)n * Q + q];
       if (pp < P) {
         const int64_t r = (int64_t)pp * N + n;
@@ -704,12 +706,12 @@ __global__ __launch_bounds__(1024) void enc_combine_bwd_vq_kernel(const float* _
       }
     }
   }
-  part[sl][threadIdx.x & 63] = acc;
+  part[sl][c] = acc;
   __syncthreads();
   if (sl == 0 && j < H) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+    for (int k = 0; k < 64; ++k) t += part[k][c];
     dvq[((int64_t)pp * Q + q) * H + j] = t;
   }
 }
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(1024) void enc_combine_bwd_vq_kernel(const float* _
 int enc_combine_bwd(const float* dpre, const float* qc, float* doffW, float* dxW, float* dvq, int P, int N, int Q, int H,
                     hipStream_t stream) {
   hipLaunchKernelGGL(enc_combine_bwd_kernel, dim3(N), dim3(128), 0, stream, dpre, doffW, dxW, P, N, H);
-  hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3((H + 63) / 64, 2 * P * Q), dim3(1024), 0, stream, dpre, qc, dvq, P,
+  hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3((H + 15) / 16, 2 * P * Q), dim3(1024), 0, stream, dpre, qc, dvq, P,
                      N, Q, H);
   CRADLE_CHECK_LAUNCH("enc_combine_bwd");
   return CRADLE_OK;
@@ -782,24 +784,26 @@ int sum_over_groups_to_cols(const float* da, int groups, int T, int H, float* dW
 // out[p, :] = sum_n w[n] da[p*N + n, :]   (gradient of the per-particle bad-variant shift)
 __global__ __launch_bounds__(1024) void weighted_rowgroup_sum_kernel(const float* __restrict__ da, const float* __restrict__ w,
                                                                      int N, int H, float* __restrict__ out) {
-  __shared__ float part[16][64];
+  // 16 columns x 64 row slices per block: 4x the blocks of a 64 x 16 arrangement for these short-wide sums
+  __shared__ float part[64][17];
   const int p = blockIdx.y;
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + c;
   float acc = 0.f;
   if (j < H)
-    for (int n = sl; n < N; n += 16) acc = fmaf(w[n], da[((int64_t)p * N + n) * H + j], acc);
-  part[sl][threadIdx.x & 63] = acc;
+    for (int n = sl; n < N; n += 64) acc = fmaf(w[n], da[((int64_t)p * N + n) * H + j], acc);
+  part[sl][c] = acc;
   __syncthreads();
   if (sl == 0 && j < H) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+    for (int k = 0; k < 64; ++k) t += part[k][c];
     out[(int64_t)p * H + j] = t;
   }
 }
 
 int weighted_rowgroup_sum(const float* da, const float* w, int P, int N, int H, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(weighted_rowgroup_sum_kernel, dim3((H + 63) / 64, P), dim3(1024), 0, stream, da, w, N, H, out);
+  hipLaunchKernelGGL(weighted_rowgroup_sum_kernel, dim3((H + 15) / 16, P), dim3(1024), 0, stream, da, w, N, H, out);
   CRADLE_CHECK_LAUNCH("weighted_rowgroup_sum_kernel");
   return CRADLE_OK;
 }

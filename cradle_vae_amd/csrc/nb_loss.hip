@@ -192,21 +192,21 @@ __global__ void nb_gene_consts_kernel(const float* __restrict__ log_c, float* __
 }
 
 // Deterministic column sum of the (rows, G) partials written by nb_rows_kernel:
-// 64 columns x 16 row slices per block.
+// 16 columns x 64 row slices per block (G/16 blocks: enough to cover the chip at G = 5000).
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part, int rows, int G,
                                                        float* __restrict__ out, int accumulate) {
-  __shared__ float sm[16][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rg = threadIdx.x >> 6;
+  __shared__ float sm[64][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + c;
   float acc = 0.f;
   if (col < G)
-    for (int r = rg; r < rows; r += 16) acc += part[(int64_t)r * G + col];
-  sm[rg][threadIdx.x & 63] = acc;
+    for (int r = rg; r < rows; r += 64) acc += part[(int64_t)r * G + col];
+  sm[rg][c] = acc;
   __syncthreads();
   if (rg == 0 && col < G) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += sm[k][threadIdx.x];
+    for (int k = 0; k < 64; ++k) t += sm[k][c];
     out[col] = accumulate ? out[col] + t : t;
   }
 }
@@ -324,7 +324,7 @@ int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, floa
                             P, N, G, PS, stream);
   if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_kernel, dim3((G + 63) / 64), dim3(1024), 0, stream, workspace, N * PS, G, dlog_c,
+  hipLaunchKernelGGL(colsum_kernel, dim3((G + 15) / 16), dim3(1024), 0, stream, workspace, N * PS, G, dlog_c,
                      accumulate_dlog_c);
   CRADLE_CHECK_LAUNCH("colsum_kernel");
   return CRADLE_OK;
