@@ -51,6 +51,8 @@ def build(shape, device, seed):
         embedding_encoder_n_layers=shape.embedding_encoder_n_layers,
         embedding_encoder_n_hidden=shape.embedding_encoder_n_hidden, x_normalization_stats=stats)
     lm = cradle_vae_ELBOLossModule(model=model, guide=guide, beta=shape.beta).to(device)
+    # what trainer.fit takes from the data set (data.TensorPerturbationDataset.max_dosages_per_cell)
+    lm.max_dosages_per_cell = max(1, int((batch["D"] != 0).sum(1).max().item()))
     return lm, batch
 
 
@@ -72,9 +74,12 @@ def k1_pmc_traffic(G, N, P):
     return d.get("traffic_bytes")
 
 
-def gemm_flops_fwd(s):
-    """Forward MLP GEMM flops of one step in the minimal form of SURVEY 8(d) (2 flops per MAC)."""
+def gemm_flops_fwd(s, kmax=None):
+    """Forward MLP GEMM flops of one step in the minimal form of SURVEY 8(d) (2 flops per MAC); the
+    embedding encoder is counted for the treatment slots the step evaluates."""
     N, P, G, T, L = s.n_cells, s.n_particles, s.n_phenos, s.n_treatments, s.n_latent
+    if kmax:
+        T = min(T, N * kmax)
     He, Hd, Hm = s.basal_encoder_n_hidden, s.decoder_n_hidden, s.embedding_encoder_n_hidden
     f_enc = 2 * 2 * N * G * He + 3 * 2 * P * N * (2 * L * He + 2 * He * L)
     f_dec = 2 * P * N * (3 * L * Hd + Hd * Hd * max(s.decoder_n_layers, 1) + Hd * G)
@@ -247,7 +252,7 @@ def main():
         # MFMA side: minimal-form GEMM flops of the step (fwd+bwd = 3x fwd) over the whole
         # step time, against the dense fp32 matrix-core peak -- a lower bound on MFMA utilisation
         # while the GEMMs run, since the step time also holds every non-GEMM kernel.
-        gf = gemm_flops_fwd(shape) * 3
+        gf = gemm_flops_fwd(shape, lm.max_dosages_per_cell) * 3
         mfma = {"flops_per_step": gf, "achieved": gf / (elapsed / args.steps) / 1e12, "peak": MFMA_F32_PEAK_TF,
                 "unit": "TFLOP/s", "frac": gf / (elapsed / args.steps) / 1e12 / MFMA_F32_PEAK_TF,
                 "note": "minimal-form MLP GEMM flops (SURVEY 8d) / whole step time; fp32 v_mfma_f32_32x32x2_f32"}
@@ -277,6 +282,7 @@ def main():
                             f"T={shape.n_treatments}, L={shape.n_latent}, H={shape.decoder_n_hidden}",
                 "step_impl": stepper.impl, "hip_graph": bool(stepper.fused is not None and stepper.fused.use_graph),
                 "decoder_variants_per_cell": V, "parallelism": f"dp{world}",
+                "treatment_slots": min(shape.n_treatments, N * lm.max_dosages_per_cell),
                 "loss": float(loss),
             },
             "roofline": roofline,

@@ -50,28 +50,47 @@ __global__ __launch_bounds__(64) void dosage_rows_kernel(const float* __restrict
   if (lane == 0 && base > kmax) atomicOr(flags, 1);
 }
 
-__global__ __launch_bounds__(1024) void scan_counts_kernel(const int* __restrict__ tcount, int T, int* __restrict__ tstart) {
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int* __restrict__ tcount, int T, int* __restrict__ tstart,
+                                                           int Tc, int* __restrict__ tmap, int* __restrict__ tpos,
+                                                           int* __restrict__ flags) {
   __shared__ int part[1024];
   __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int c = 0; c < T; c += 1024) {
-    const int t = c + threadIdx.x;
-    const int v = t < T ? tcount[t] : 0;
-    part[threadIdx.x] = v;
+  // pass 0: exclusive scan of the counts (CSC column starts); pass 1 (compact axis only): exclusive
+  // scan of "has a cell" -> slot of every present treatment, ascending
+  for (int pass = 0; pass < (tmap ? 2 : 1); ++pass) {
+    if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    for (int c = 0; c < T; c += 1024) {
+      const int t = c + threadIdx.x;
+      const int cnt = t < T ? tcount[t] : 0;
+      const int v = pass == 0 ? cnt : (cnt > 0 ? 1 : 0);
+      part[threadIdx.x] = v;
       __syncthreads();
-      part[threadIdx.x] += add;
+      for (int off = 1; off < 1024; off <<= 1) {
+        int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+      }
+      if (t < T) {
+        const int ex = carry + part[threadIdx.x] - v;
+        if (pass == 0) {
+          tstart[t] = ex;
+        } else if (v && ex < Tc) {
+          tpos[t] = ex;
+          tmap[ex] = t;
+        } else {
+          tpos[t] = -1;
+          if (v) atomicOr(flags, 1);  // more present treatments than slots: kmax too small
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 1023) carry += part[1023];
       __syncthreads();
     }
-    if (t < T) tstart[t] = carry + part[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += part[1023];
+    if (pass == 0 && threadIdx.x == 0) tstart[T] = carry;
     __syncthreads();
   }
-  if (threadIdx.x == 0) tstart[T] = carry;
 }
 
 // One wave per treatment scans the ELL entries in (cell, slot) order, 64 at a time; the ballot
@@ -99,16 +118,23 @@ __global__ __launch_bounds__(256) void csc_fill_kernel(const int* __restrict__ e
 int build_dosage_plan(const float* D, int N, int T, const DosagePlan& plan, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(plan.tcount, 0, sizeof(int) * T, stream);
   if (e == hipSuccess) e = hipMemsetAsync(plan.flags, 0, sizeof(int), stream);
+  if (e == hipSuccess && plan.tmap) e = hipMemsetAsync(plan.tmap, 0xFF, sizeof(int) * plan.Tc, stream);  // -1
   if (e != hipSuccess) {
     cradle_set_error("build_dosage_plan: memset failed: %s", hipGetErrorString(e));
     return CRADLE_ERR_HIP;
   }
   hipLaunchKernelGGL(dosage_rows_kernel, dim3(N), dim3(64), 0, stream, D, N, T, plan.kmax, plan.ell_idx, plan.ell_val,
                      plan.tcount, plan.flags);
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, plan.tcount, T, plan.tstart);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, plan.tcount, T, plan.tstart, plan.Tc, plan.tmap,
+                     plan.tpos, plan.flags);
+  CRADLE_CHECK_LAUNCH("build_dosage_plan");
+  return CRADLE_OK;
+}
+
+int build_dosage_plan_csc(int N, int T, const DosagePlan& plan, hipStream_t stream) {
   hipLaunchKernelGGL(csc_fill_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, plan.ell_idx, plan.ell_val,
                      N * plan.kmax, plan.kmax, T, plan.tstart, plan.csc_cell, plan.csc_val);
-  CRADLE_CHECK_LAUNCH("build_dosage_plan");
+  CRADLE_CHECK_LAUNCH("csc_fill_kernel");
   return CRADLE_OK;
 }
 
@@ -121,7 +147,7 @@ int build_dosage_plan(const float* D, int N, int T, const DosagePlan& plan, hipS
 __global__ __launch_bounds__(256) void cell_prep_kernel(const float* __restrict__ qc, const float* __restrict__ D_obs,
                                                         const float* __restrict__ qc_obs, const int* __restrict__ tcount,
                                                         float alpha_fixed, int P, int N, int T, int Q, CellPrep o,
-                                                        int* __restrict__ flags) {
+                                                        int* __restrict__ flags, int Tc, const int* __restrict__ tmap) {
   __shared__ float red[8];
   __shared__ float red2[8];
   float qsum = 0.f, nzc = 0.f;
@@ -159,6 +185,17 @@ __global__ __launch_bounds__(256) void cell_prep_kernel(const float* __restrict_
     o.cw[t] = c;
     o.coefT[t] = -c * inv_pn;
   }
+  for (int j = threadIdx.x; j < Tc; j += 256) {  // the same weights by slot
+    const int t = tmap ? tmap[j] : j;
+    float c = 0.f;
+    if (t >= 0) {
+      float s = 1.0f / D_obs[t];
+      if (isinf(s)) s = 0.f;
+      c = (float)tcount[t] * s;
+    }
+    o.cwc[j] = c;
+    o.coefTc[j] = -c * inv_pn;
+  }
   for (int q = threadIdx.x; q < Q; q += 256) {
     float s = 1.0f / qc_obs[q];
     if (isinf(s)) s = 0.f;
@@ -169,9 +206,9 @@ __global__ __launch_bounds__(256) void cell_prep_kernel(const float* __restrict_
 }
 
 int cell_prep(const float* qc, const float* D_obs, const float* qc_obs, const int* tcount, float alpha_fixed, int P,
-              int N, int T, int Q, const CellPrep& out, int* flags, hipStream_t stream) {
+              int N, int T, int Q, const CellPrep& out, int* flags, int Tc, const int* tmap, hipStream_t stream) {
   hipLaunchKernelGGL(cell_prep_kernel, dim3(1), dim3(256), 0, stream, qc, D_obs, qc_obs, tcount, alpha_fixed, P, N, T, Q,
-                     out, flags);
+                     out, flags, Tc, tmap);
   CRADLE_CHECK_LAUNCH("cell_prep_kernel");
   return CRADLE_OK;
 }
@@ -217,23 +254,34 @@ __device__ __forceinline__ float sanitize(float v) { return finitef_(v) ? v : 0.
 
 __global__ __launch_bounds__(256) void mask_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ u,
                                                        const float* __restrict__ p0, float tau, float* __restrict__ mask,
-                                                       float* __restrict__ soft, float* __restrict__ S, int rows, int T, int L) {
+                                                       float* __restrict__ soft, float* __restrict__ S, int rows, int T, int Tc,
+                                                       const int* __restrict__ tmap, int L) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const int t = row % T;
+  const int j = row % Tc, pp = row / Tc;
+  const int t = tmap ? tmap[j] : j;
+  if (t < 0) {  // unused slot
+    for (int l = lane; l < L; l += 64) {
+      mask[(int64_t)row * L + l] = 0.f;
+      soft[(int64_t)row * L + l] = 0.f;
+    }
+    if (lane == 0) S[row] = 0.f;
+    return;
+  }
+  const float* urow = u + ((int64_t)pp * T + t) * L;
   float acc = 0.f;
   for (int l = lane; l < L; l += 64) {
     const float lg = sanitize(logits[t * L + l]);
     const float p = clamp_probs(sigmoidf_(lg));
     const float lq = logf(p) - log1pf(-p);
-    const float uu = clamp_probs(u[(int64_t)row * L + l]);
+    const float uu = clamp_probs(urow[l]);
     const float y = (logf(uu) - log1pf(-uu) + lq) / tau;
     const float s = clamp_probs(sigmoidf_(y));
     const float m = rintf(s);
     mask[(int64_t)row * L + l] = m;
     soft[(int64_t)row * L + l] = s;
-    const float pp = p0[t * L + l];
-    const float lp = logf(pp / (1.0f - pp));  // torch.logit
+    const float pp0 = p0[t * L + l];
+    const float lp = logf(pp0 / (1.0f - pp0));  // torch.logit
     acc += (m * lp - softplusf_(lp)) - (m * lq - softplusf_(lq));
   }
   acc = wave_sum(acc);
@@ -241,10 +289,10 @@ __global__ __launch_bounds__(256) void mask_fwd_kernel(const float* __restrict__
 }
 
 int mask_fwd(const float* logits, const float* u, const float* p_mask_probs, float tau, float* mask, float* soft,
-             float* S, int PP, int T, int L, hipStream_t stream) {
-  const int rows = PP * T;
+             float* S, int PP, int T, int Tc, const int* tmap, int L, hipStream_t stream) {
+  const int rows = PP * Tc;
   hipLaunchKernelGGL(mask_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, u, p_mask_probs, tau, mask, soft,
-                     S, rows, T, L);
+                     S, rows, T, Tc, tmap, L);
   CRADLE_CHECK_LAUNCH("mask_fwd_kernel");
   return CRADLE_OK;
 }
@@ -257,12 +305,13 @@ __global__ __launch_bounds__(256) void mask_bwd_kernel(const float* __restrict__
                                                        float tau, const float* __restrict__ mask, const float* __restrict__ soft,
                                                        const float* __restrict__ da, const float* __restrict__ db,
                                                        const float* __restrict__ coefT, float* __restrict__ dlogits, int PP,
-                                                       int P, int T, int L) {
+                                                       int P, int T, int Tc, const int* __restrict__ tpos, int L) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= T * L) return;
-  const int t = i / L;
+  const int t = i / L, l = i % L;
+  const int slot = tpos ? tpos[t] : t;
   const float raw = logits[i];
-  if (!finitef_(raw)) {  // sanitize_tensor replaced it by a constant
+  if (slot < 0 || !finitef_(raw)) {  // no cell of this treatment in the batch / sanitize_tensor made it a constant
     dlogits[i] = 0.f;
     return;
   }
@@ -275,7 +324,7 @@ __global__ __launch_bounds__(256) void mask_bwd_kernel(const float* __restrict__
   const float ct = coefT[t];
   float g = 0.f;
   for (int pp = 0; pp < PP; ++pp) {
-    const int64_t j = (int64_t)pp * T * L + i;
+    const int64_t j = ((int64_t)pp * Tc + slot) * L + l;
     const float m = mask[j], s = soft[j];
     float dm = da[j] + db[j];
     if (pp < P) dm += ct * (lp - lq);          // d/dm [log p(m) - log q(m)]
@@ -288,10 +337,10 @@ __global__ __launch_bounds__(256) void mask_bwd_kernel(const float* __restrict__
 }
 
 int mask_bwd(const float* logits, const float* p_mask_probs, float tau, const float* mask, const float* soft,
-             const float* dmask_a, const float* dmask_b, const float* coefT, float* dlogits, int PP, int P, int T, int L,
-             hipStream_t stream) {
+             const float* dmask_a, const float* dmask_b, const float* coefT, float* dlogits, int PP, int P, int T, int Tc,
+             const int* tpos, int L, hipStream_t stream) {
   hipLaunchKernelGGL(mask_bwd_kernel, dim3((T * L + 255) / 256), dim3(256), 0, stream, logits, p_mask_probs, tau, mask,
-                     soft, dmask_a, dmask_b, coefT, dlogits, PP, P, T, L);
+                     soft, dmask_a, dmask_b, coefT, dlogits, PP, P, T, Tc, tpos, L);
   CRADLE_CHECK_LAUNCH("mask_bwd_kernel");
   return CRADLE_OK;
 }
@@ -318,19 +367,30 @@ __device__ __forceinline__ GaussVals gauss_vals(float mean_raw, float lv_raw) {
   return g;
 }
 
-// q(E|M): rows = PP*T, also writes mask*E for the gathers (model.py:121, guide :186-188).
+// q(E|M): rows = PP*Tc (particle, slot), also writes mask*E for the gathers (model.py:121, guide :186-188).
 __global__ __launch_bounds__(256) void gaussE_fwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
                                                          const float* __restrict__ mask, const float* __restrict__ ploc,
                                                          const float* __restrict__ pscale, float* __restrict__ E,
                                                          float* __restrict__ sd, float* __restrict__ ME, float* __restrict__ S,
-                                                         int rows, int T, int L) {
+                                                         int rows, int T, int Tc, const int* __restrict__ tmap, int L) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const int t = row % T;
+  const int j = row % Tc, pp = row / Tc;
+  const int t = tmap ? tmap[j] : j;
+  if (t < 0) {  // unused slot
+    for (int l = lane; l < L; l += 64) {
+      E[(int64_t)row * L + l] = 0.f;
+      sd[(int64_t)row * L + l] = 1.f;
+      ME[(int64_t)row * L + l] = 0.f;
+    }
+    if (lane == 0) S[row] = 0.f;
+    return;
+  }
+  const float* erow = eps + ((int64_t)pp * T + t) * L;
   float acc = 0.f;
   for (int l = lane; l < L; l += 64) {
     const GaussVals g = gauss_vals(heads[(int64_t)row * 2 * L + l], heads[(int64_t)row * 2 * L + L + l]);
-    const float ep = eps[(int64_t)row * L + l];
+    const float ep = erow[l];
     const float s = g.mean + g.sd * ep;
     E[(int64_t)row * L + l] = s;
     sd[(int64_t)row * L + l] = g.sd;
@@ -344,10 +404,10 @@ __global__ __launch_bounds__(256) void gaussE_fwd_kernel(const float* __restrict
 }
 
 int gaussE_fwd(const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale, float* E,
-               float* sd, float* ME, float* S, int PP, int T, int L, hipStream_t stream) {
-  const int rows = PP * T;
+               float* sd, float* ME, float* S, int PP, int T, int Tc, const int* tmap, int L, hipStream_t stream) {
+  const int rows = PP * Tc;
   hipLaunchKernelGGL(gaussE_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, heads, eps, mask, ploc, pscale, E, sd,
-                     ME, S, rows, T, L);
+                     ME, S, rows, T, Tc, tmap, L);
   CRADLE_CHECK_LAUNCH("gaussE_fwd_kernel");
   return CRADLE_OK;
 }
@@ -363,16 +423,24 @@ __global__ __launch_bounds__(256) void gaussE_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ mask, const float* __restrict__ ploc,
                                                          const float* __restrict__ pscale, const float* __restrict__ E,
                                                          const float* __restrict__ sd, const float* __restrict__ dME,
-                                                         const float* __restrict__ coefT, float* __restrict__ dheads,
-                                                         float* __restrict__ dmask, int PP, int P, int T, int L) {
+                                                         const float* __restrict__ coefTc, float* __restrict__ dheads,
+                                                         float* __restrict__ dmask, int PP, int P, int T, int Tc,
+                                                         const int* __restrict__ tmap, int L) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)PP * T * L) return;
+  if (i >= (int64_t)PP * Tc * L) return;
   const int l = i % L;
   const int64_t row = i / L;
-  const int t = row % T, pp = row / T;
+  const int j = row % Tc, pp = row / Tc;
+  const int t = tmap ? tmap[j] : j;
+  if (t < 0) {  // unused slot: nothing flows back
+    dmask[i] = 0.f;
+    dheads[row * 2 * L + l] = 0.f;
+    dheads[row * 2 * L + L + l] = 0.f;
+    return;
+  }
   const GaussVals g = gauss_vals(heads[row * 2 * L + l], heads[row * 2 * L + L + l]);
-  const float s = E[i], ep = eps[i], dme = dME[i];
-  const float coef = pp < P ? coefT[t] : 0.f;
+  const float s = E[i], ep = eps[((int64_t)pp * T + t) * L + l], dme = dME[i];
+  const float coef = pp < P ? coefTc[j] : 0.f;
   const float pl = ploc[t * L + l], ps = pscale[t * L + l];
   const float ds = dme * mask[i] + coef * (-(s - pl) / (ps * ps));
   dmask[i] = dme * s;
@@ -383,11 +451,11 @@ __global__ __launch_bounds__(256) void gaussE_bwd_kernel(const float* __restrict
 }
 
 int gaussE_bwd(const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale,
-               const float* E, const float* sd, const float* dME, const float* coefT, float* dheads, float* dmask, int PP,
-               int P, int T, int L, hipStream_t stream) {
-  const int64_t n = (int64_t)PP * T * L;
+               const float* E, const float* sd, const float* dME, const float* coefTc, float* dheads, float* dmask, int PP,
+               int P, int T, int Tc, const int* tmap, int L, hipStream_t stream) {
+  const int64_t n = (int64_t)PP * Tc * L;
   hipLaunchKernelGGL(gaussE_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, heads, eps, mask, ploc,
-                     pscale, E, sd, dME, coefT, dheads, dmask, PP, P, T, L);
+                     pscale, E, sd, dME, coefTc, dheads, dmask, PP, P, T, Tc, tmap, L);
   CRADLE_CHECK_LAUNCH("gaussE_bwd_kernel");
   return CRADLE_OK;
 }
@@ -575,16 +643,17 @@ int zhead_bwd(const float* heads, const float* eps, const float* z, int64_t ldz,
 __global__ __launch_bounds__(64) void gather_offsets_kernel(const float* __restrict__ ME, const int* __restrict__ ell_idx,
                                                             const float* __restrict__ ell_val, int kmax, float* __restrict__ offA,
                                                             int64_t ldA, float* __restrict__ offB, int64_t ldB, int P, int N,
-                                                            int T, int L) {
+                                                            int Tc, const int* __restrict__ tpos, int L) {
   const int n = blockIdx.x, pp = blockIdx.y;
   float* out = pp < P ? offA + ((int64_t)pp * N + n) * ldA : offB + ((int64_t)(pp - P) * N + n) * ldB;
-  const float* tab = ME + (int64_t)pp * T * L;
+  const float* tab = ME + (int64_t)pp * Tc * L;
   for (int l = threadIdx.x; l < L; l += 64) {
     float acc = 0.f;
     for (int k = 0; k < kmax; ++k) {
       const int t = ell_idx[n * kmax + k];
       if (t < 0) break;
-      acc = fmaf(ell_val[n * kmax + k], tab[(int64_t)t * L + l], acc);
+      const int slot = tpos ? tpos[t] : t;
+      if (slot >= 0) acc = fmaf(ell_val[n * kmax + k], tab[(int64_t)slot * L + l], acc);
     }
     out[l] = acc;
   }
@@ -592,8 +661,9 @@ __global__ __launch_bounds__(64) void gather_offsets_kernel(const float* __restr
 
 int gather_offsets(const float* ME, const DosagePlan& plan, float* offA, int64_t ldA, float* offB, int64_t ldB, int PP,
                    int P, int N, int T, int L, hipStream_t stream) {
+  (void)T;
   hipLaunchKernelGGL(gather_offsets_kernel, dim3(N, PP), dim3(64), 0, stream, ME, plan.ell_idx, plan.ell_val, plan.kmax,
-                     offA, ldA, offB, ldB, P, N, T, L);
+                     offA, ldA, offB, ldB, P, N, plan.Tc, plan.tpos, L);
   CRADLE_CHECK_LAUNCH("gather_offsets_kernel");
   return CRADLE_OK;
 }
@@ -603,10 +673,11 @@ __global__ __launch_bounds__(256) void scatter_offsets_kernel(const int* __restr
                                                              const float* __restrict__ csc_val, const float* __restrict__ a1,
                                                              int64_t ld1, const float* __restrict__ a2, int64_t ld2,
                                                              const float* __restrict__ b1, int64_t ldb1, float* __restrict__ dME,
-                                                             int P, int N, int T, int L) {
-  const int t = blockIdx.x, pp = blockIdx.y;
-  const int e0 = tstart[t], e1 = tstart[t + 1];
-  float* out = dME + ((int64_t)pp * T + t) * L;
+                                                             int P, int N, int Tc, const int* __restrict__ tmap, int L) {
+  const int j = blockIdx.x, pp = blockIdx.y;
+  const int t = tmap ? tmap[j] : j;
+  const int e0 = t >= 0 ? tstart[t] : 0, e1 = t >= 0 ? tstart[t + 1] : 0;  // unused slot: zeros
+  float* out = dME + ((int64_t)pp * Tc + j) * L;
   for (int l = threadIdx.x; l < L; l += blockDim.x) {
     float acc = 0.f;
     for (int e = e0; e < e1; ++e) {
@@ -623,8 +694,9 @@ __global__ __launch_bounds__(256) void scatter_offsets_kernel(const int* __restr
 int scatter_offsets(const DosagePlan& plan, const float* a1, int64_t ld1, const float* a2, int64_t ld2, const float* b1,
                     int64_t ldb1, float* dME, int PP, int P, int N, int T, int L, hipStream_t stream) {
   const int nt = L <= 64 ? 64 : (L <= 128 ? 128 : 256);  // one pass over the latent columns
-  hipLaunchKernelGGL(scatter_offsets_kernel, dim3(T, PP), dim3(nt), 0, stream, plan.tstart, plan.csc_cell, plan.csc_val, a1,
-                     ld1, a2, ld2, b1, ldb1, dME, P, N, T, L);
+  (void)T;
+  hipLaunchKernelGGL(scatter_offsets_kernel, dim3(plan.Tc, PP), dim3(nt), 0, stream, plan.tstart, plan.csc_cell, plan.csc_val,
+                     a1, ld1, a2, ld2, b1, ldb1, dME, P, N, plan.Tc, plan.tmap, L);
   CRADLE_CHECK_LAUNCH("scatter_offsets_kernel");
   return CRADLE_OK;
 }
@@ -753,17 +825,35 @@ int transpose_cols(const float* W, int64_t ldw, int rows, int col0, int cols, fl
   return CRADLE_OK;
 }
 
-// dW[h, col0 + t] = sum_groups da[g*T + t, h]   (gradient of the one-hot block)
-__global__ __launch_bounds__(256) void sum_groups_to_cols_kernel(const float* __restrict__ da, int groups, int T, int H,
-                                                                 float* __restrict__ dW, int64_t lddw, int col0) {
+// out[j, r] = W[r, col0 + tmap[j]] (0 for unused slots): the one-hot block by slot
+__global__ __launch_bounds__(256) void gather_cols_kernel(const float* __restrict__ W, int64_t ldw, int rows, int col0,
+                                                          const int* __restrict__ tmap, float* __restrict__ out) {
+  const int j = blockIdx.x;
+  const int t = tmap[j];
+  for (int r = threadIdx.x; r < rows; r += 256) out[(int64_t)j * rows + r] = t >= 0 ? W[(int64_t)r * ldw + col0 + t] : 0.f;
+}
+
+int gather_cols(const float* W, int64_t ldw, int rows, int col0, int Tc, const int* tmap, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(Tc), dim3(256), 0, stream, W, ldw, rows, col0, tmap, out);
+  CRADLE_CHECK_LAUNCH("gather_cols_kernel");
+  return CRADLE_OK;
+}
+
+// dW[h, col0 + t] = sum_groups da[g*Tc + slot(t), h]   (gradient of the one-hot block; 0 for absent treatments)
+__global__ __launch_bounds__(256) void sum_groups_to_cols_kernel(const float* __restrict__ da, int groups, int T, int Tc,
+                                                                 const int* __restrict__ tpos, int H, float* __restrict__ dW,
+                                                                 int64_t lddw, int col0) {
   __shared__ float tile[32][33];
   const int t0 = blockIdx.x * 32, h0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += 8) {
     const int t = t0 + i, h = h0 + tx;
     float s = 0.f;
-    if (t < T && h < H)
-      for (int g = 0; g < groups; ++g) s += da[((int64_t)g * T + t) * H + h];
+    if (t < T && h < H) {
+      const int slot = tpos ? tpos[t] : t;
+      if (slot >= 0)
+        for (int g = 0; g < groups; ++g) s += da[((int64_t)g * Tc + slot) * H + h];
+    }
     tile[i][tx] = s;
   }
   __syncthreads();
@@ -773,10 +863,10 @@ __global__ __launch_bounds__(256) void sum_groups_to_cols_kernel(const float* __
   }
 }
 
-int sum_over_groups_to_cols(const float* da, int groups, int T, int H, float* dW, int64_t lddw, int col0,
-                            hipStream_t stream) {
-  hipLaunchKernelGGL(sum_groups_to_cols_kernel, dim3((T + 31) / 32, (H + 31) / 32), dim3(256), 0, stream, da, groups, T, H,
-                     dW, lddw, col0);
+int sum_over_groups_to_cols(const float* da, int groups, int T, int Tc, const int* tpos, int H, float* dW, int64_t lddw,
+                            int col0, hipStream_t stream) {
+  hipLaunchKernelGGL(sum_groups_to_cols_kernel, dim3((T + 31) / 32, (H + 31) / 32), dim3(256), 0, stream, da, groups, T, Tc,
+                     tpos, H, dW, lddw, col0);
   CRADLE_CHECK_LAUNCH("sum_groups_to_cols_kernel");
   return CRADLE_OK;
 }

@@ -68,8 +68,16 @@ struct DosagePlan {
   float* csc_val;  // (N*kmax)
   int* flags;      // bit 0: a cell has more than kmax non-zero dosages; bit 1: qc not in {0,1}
   int kmax;
+  // Compact treatment axis: only treatments with a cell in the batch enter the loss or any gradient
+  // (their plate weight is zero otherwise, loss_modules.py:224-232), so q(M), q(E|M) are evaluated for
+  // the Tc = min(T, N*kmax) slots of tmap only.  Tc == T: identity, tmap/tpos are NULL.
+  int Tc;
+  int* tmap;       // (Tc) slot -> treatment, ascending, -1 = unused slot
+  int* tpos;       // (T) treatment -> slot or -1
 };
+// first part: ELL rows, counts, scan, compact map (what the forward gathers need); second part: CSC
 int build_dosage_plan(const float* D, int N, int T, const DosagePlan& plan, hipStream_t stream);
+int build_dosage_plan_csc(int N, int T, const DosagePlan& plan, hipStream_t stream);
 
 struct CellPrep {
   float* alpha;   // (1)
@@ -80,24 +88,29 @@ struct CellPrep {
   float* cwq;     // (Q)
   float* coefT;   // (T) -cw / (P*N)
   float* coefQ;   // (Q)
+  float* cwc;     // (Tc) cw by slot (0 for unused slots)
+  float* coefTc;  // (Tc) coefT by slot
 };
 int cell_prep(const float* qc, const float* D_obs, const float* qc_obs, const int* tcount, float alpha_fixed, int P,
-              int N, int T, int Q, const CellPrep& out, int* flags, hipStream_t stream);
+              int N, int T, int Q, const CellPrep& out, int* flags, int Tc, const int* tmap, hipStream_t stream);
 
 int log_standardize(const float* X, const float* cfX, const float* log_mean, const float* log_scale, float* xn,
                     float* hascf, int N, int G, hipStream_t stream);
 
 // ---- elementwise.hip : sampling + log-ratio terms
+// (rows of mask / E / heads are (particle, slot) pairs: row = pp*Tc + j; noise and per-treatment tables
+//  are indexed by the treatment tmap[j])
 int mask_fwd(const float* logits, const float* u, const float* p_mask_probs, float tau, float* mask, float* soft,
-             float* S, int PP, int T, int L, hipStream_t stream);
+             float* S, int PP, int T, int Tc, const int* tmap, int L, hipStream_t stream);
 int mask_bwd(const float* logits, const float* p_mask_probs, float tau, const float* mask, const float* soft,
              const float* dmask_a, const float* dmask_b, const float* coefT, float* dlogits, int PP, int P, int T,
-             int L, hipStream_t stream);
+             int Tc, const int* tpos, int L, hipStream_t stream);
 int gaussE_fwd(const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale,
-               float* E, float* sd, float* ME, float* S, int PP, int T, int L, hipStream_t stream);
+               float* E, float* sd, float* ME, float* S, int PP, int T, int Tc, const int* tmap, int L,
+               hipStream_t stream);
 int gaussE_bwd(const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale,
-               const float* E, const float* sd, const float* dME, const float* coefT, float* dheads, float* dmask,
-               int PP, int P, int T, int L, hipStream_t stream);
+               const float* E, const float* sd, const float* dME, const float* coefTc, float* dheads, float* dmask,
+               int PP, int P, int T, int Tc, const int* tmap, int L, hipStream_t stream);
 int qce_fwd(const float* heads, const float* eps, const float* ploc, const float* pscale, float* qcE, float* sd,
             float* S, float* qsum, int PP, int P, int Q, int L, hipStream_t stream);
 int qce_bwd(const float* heads, const float* eps, const float* ploc, const float* pscale, const float* qcE,
@@ -120,8 +133,9 @@ int enc_combine_bwd(const float* dpre, const float* qc, float* doffW, float* dxW
 
 // ---- elementwise.hip : small helpers
 int transpose_cols(const float* W, int64_t ldw, int rows, int col0, int cols, float* out, hipStream_t stream);
-int sum_over_groups_to_cols(const float* da, int groups, int T, int H, float* dW, int64_t lddw, int col0,
-                            hipStream_t stream);
+int gather_cols(const float* W, int64_t ldw, int rows, int col0, int Tc, const int* tmap, float* out, hipStream_t stream);
+int sum_over_groups_to_cols(const float* da, int groups, int T, int Tc, const int* tpos, int H, float* dW, int64_t lddw,
+                            int col0, hipStream_t stream);
 int weighted_rowgroup_sum(const float* da, const float* w, int P, int N, int H, float* out, hipStream_t stream);
 int finalize_loss(const float* recon, const float* wrec, const float* ltz, const float* klrow, const float* Smask,
                   const float* SE, const float* Sq, const float* cw, const float* cwq, float beta, int P, int N, int T,

@@ -130,12 +130,23 @@ struct Work {
   int64_t nbws_floats;
 };
 
+// Slots of the compact treatment axis (kernels.h, DosagePlan): a batch of N cells with at most kmax
+// dosages each cannot hold more than N*kmax distinct treatments.
+int compact_slots(const cradle_step_desc& d) {
+  const int64_t bound = (int64_t)d.N * d.kmax;
+  return bound < d.T ? (int)bound : d.T;
+}
+
 int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   Arena a(base);
   const int P = d.P, N = d.N, T = d.T, L = d.L, Q = d.Q, G = d.G, He = d.He, Hm = d.Hm, Hd = d.Hd;
   const int PP = 2 * P;
-  const int64_t PN = (int64_t)P * N, PT = (int64_t)PP * T;
+  const int Tc = compact_slots(d);
+  const int64_t PN = (int64_t)P * N, PT = (int64_t)PP * Tc;
   w.plan.kmax = d.kmax;
+  w.plan.Tc = Tc;
+  w.plan.tmap = Tc < T ? a.take<int>(Tc) : nullptr;
+  w.plan.tpos = Tc < T ? a.take<int>(T) : nullptr;
   w.plan.ell_idx = a.take<int>((int64_t)N * d.kmax);
   w.plan.ell_val = a.take<float>((int64_t)N * d.kmax);
   w.plan.tcount = a.take<int>(T);
@@ -151,12 +162,14 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   w.cp.cwq = a.take<float>(Q);
   w.cp.coefT = a.take<float>(T);
   w.cp.coefQ = a.take<float>(Q);
+  w.cp.cwc = a.take<float>(Tc);
+  w.cp.coefTc = a.take<float>(Tc);
   w.hascf = a.take<float>(N);
   w.gene_consts = a.take<float>(3ll * G);
   w.mask = a.take<float>(PT * L);
   w.soft = a.take<float>(PT * L);
   w.Smask = a.take<float>(PT);
-  w.W0tT = a.take<float>((int64_t)T * Hm);
+  w.W0tT = a.take<float>((int64_t)Tc * Hm);
   for (int k = 0; k < d.emb.n_layers; ++k) {
     w.yE[k] = a.take<float>(PT * Hm);
     w.rE[k] = k ? a.take<float>(PT * Hm) : nullptr;
@@ -292,6 +305,28 @@ struct Ctx {
     hipEvent_t e = ev[nev++];
     if (hipEventRecord(e, st[src]) != hipSuccess || hipStreamWaitEvent(st[dst], e, 0) != hipSuccess) {
       cradle_set_error("elbo_step: event record/wait failed");
+      rc = CRADLE_ERR_HIP;
+    }
+  }
+  // the two halves of after(): a point on `src` that several later waits can refer to
+  hipEvent_t record(int src) {
+    if (rc) return nullptr;
+    if (nev >= kMaxEvents) {
+      cradle_set_error("elbo_step: out of fork/join events");
+      rc = CRADLE_ERR_HIP;
+      return nullptr;
+    }
+    hipEvent_t e = ev[nev++];
+    if (hipEventRecord(e, st[src]) != hipSuccess) {
+      cradle_set_error("elbo_step: event record failed");
+      rc = CRADLE_ERR_HIP;
+    }
+    return e;
+  }
+  void wait(int dst, hipEvent_t e) {
+    if (rc || !e) return;
+    if (hipStreamWaitEvent(st[dst], e, 0) != hipSuccess) {
+      cradle_set_error("elbo_step: event wait failed");
       rc = CRADLE_ERR_HIP;
     }
   }
@@ -441,7 +476,8 @@ enum { PH_PRE = 1, PH_K1 = 2, PH_POST = 4, PH_ALL = 7 };
 
 int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   const int P = d.P, N = d.N, T = d.T, L = d.L, Q = d.Q, G = d.G, He = d.He, Hm = d.Hm, Hd = d.Hd;
-  const int PP = 2 * P, PN = P * N, PT = PP * T;
+  const int Tc = w.plan.Tc;
+  const int PP = 2 * P, PN = P * N, PT = PP * Tc;
   int rc = 0;
   hipStream_t s = c.st[0], s1 = c.st[1], s2 = c.st[2];
   const float* Wenc0 = d.enc.W[0];
@@ -460,11 +496,14 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   // stream 0 (caller's): dosage plan, q(M), q(E|M), gathers -- then joins both.
   c.after(1, 0);
   c.after(2, 0);
-  // the dosage plan and the per-cell weights depend on the batch only: first thing on stream 1,
-  // so that stream 0 starts with q(M) / q(E|M) straight away and meets the plan at the gather
+  // the dosage plan and the per-cell weights depend on the batch only: first thing on stream 1.
+  // Full treatment axis: stream 0 starts with q(M) / q(E|M) straight away and meets the plan at
+  // the gather.  Compact axis: q(M) needs the slot map, so stream 0 waits for the plan's first part.
   STEP(build_dosage_plan(d.D, N, T, w.plan, s1));
-  STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, s1));
-  c.after(0, 1);
+  hipEvent_t ev_plan = c.record(1);
+  STEP(build_dosage_plan_csc(N, T, w.plan, s1));
+  STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, Tc, w.plan.tmap,
+                 s1));
   STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s1));
   c.gemm(GEMM_NT, gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G), 1);  // x Wx^T, X and cfX
 
@@ -482,17 +521,24 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   c.gemm(GEMM_NT, gp(w.qcE, L, Wenc0 + G + L, ldenc, w.vq, He, PP * Q, He, L), 2);  // qc_E Wqc^T
   c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L), 2);        // bad-variant shift per particle
 
-  STEP(mask_fwd(d.q_mask_logits, d.u_mask, d.p_mask_probs, d.temperature, w.mask, w.soft, w.Smask, PP, T, L, s));
-  STEP(transpose_cols(d.emb.W[0], L + T, Hm, L, T, w.W0tT, s));
+  if (w.plan.tmap) c.wait(0, ev_plan);
+  STEP(mask_fwd(d.q_mask_logits, d.u_mask, d.p_mask_probs, d.temperature, w.mask, w.soft, w.Smask, PP, T, Tc, w.plan.tmap,
+                L, s));
+  if (w.plan.tmap)
+    STEP(gather_cols(d.emb.W[0], L + T, Hm, L, Tc, w.plan.tmap, w.W0tT, s));
+  else
+    STEP(transpose_cols(d.emb.W[0], L + T, Hm, L, T, w.W0tT, s));
   {  // layer 0: LeakyReLU(mask Wm^T + W_onehot[:, t] + b)
     GemmParams p = gp(w.mask, L, d.emb.W[0], L + T, w.yE[0], Hm, PT, Hm, L);
-    p.bias = d.emb.b[0]; p.act = 1; p.rowbias = w.W0tT; p.ld_rb = Hm; p.rb_mode = 2; p.rb_n = T;
+    p.bias = d.emb.b[0]; p.act = 1; p.rowbias = w.W0tT; p.ld_rb = Hm; p.rb_mode = 2; p.rb_n = Tc;
     c.gemm(GEMM_NT, p);
   }
   trunk_fwd(c, d.emb, PT, Hm, w.yE, w.rE);
   head_fwd(c, d.emb, PT, Hm, 2 * L, w.yE[d.emb.n_layers - 1], w.headsE);
   if (c.rc) return c.rc;
-  STEP(gaussE_fwd(w.headsE, d.eps_E, w.mask, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.ME, w.SE, PP, T, L, s));
+  STEP(gaussE_fwd(w.headsE, d.eps_E, w.mask, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.ME, w.SE, PP, T, Tc, w.plan.tmap, L,
+                  s));
+  if (!w.plan.tmap) c.wait(0, ev_plan);
   STEP(gather_offsets(w.ME, w.plan, w.zoff + L, 2 * L, w.offB, L, PP, P, N, T, L, s));     // D @ (mask*E)
   c.gemm(GEMM_NT, gp(w.zoff + L, 2 * L, Wenc0 + G, ldenc, w.offW, He, PN, He, L));         // main pass offsets
   c.gemm(GEMM_NT, gp(w.offB, L, Wenc0 + G, ldenc, w.offW + (int64_t)PN * He, He, PN, He, L));  // cf pass offsets
@@ -532,7 +578,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   }
   }  // PH_K1
   if (!(phases & PH_POST)) return CRADLE_OK;
-  STEP(finalize_loss(w.recon, w.cp.wrec, w.ltz, w.klrow, w.Smask, w.SE, w.Sq, w.cp.cw, w.cp.cwq, d.beta, P, N, T, Q,
+  STEP(finalize_loss(w.recon, w.cp.wrec, w.ltz, w.klrow, w.Smask, w.SE, w.Sq, w.cp.cwc, w.cp.cwq, d.beta, P, N, Tc, Q,
                      d.out, s));
   if (!d.compute_grads) return CRADLE_OK;
 
@@ -596,8 +642,8 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
 
   // q(E|M), q(M)
   STEP(scatter_offsets(w.plan, w.dzoff + L, 2 * L, w.doffenc, L, w.doffenc + (int64_t)PN * L, L, w.dME, PP, P, N, T, L, s));
-  STEP(gaussE_bwd(w.headsE, d.eps_E, w.mask, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.dME, w.cp.coefT, w.dheadsE, w.dmaskME,
-                  PP, P, T, L, s));
+  STEP(gaussE_bwd(w.headsE, d.eps_E, w.mask, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.dME, w.cp.coefTc, w.dheadsE, w.dmaskME,
+                  PP, P, T, Tc, w.plan.tmap, L, s));
   const float* da0E = head_trunk_bwd(c, d.emb, d.d_emb, PT, Hm, 2 * L, w.dheadsE, w.yE, w.rE, w.GE, w.daE, 0, 1, 1);
   if (c.rc) return c.rc;
   c.after(1, 0);
@@ -606,11 +652,11 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
     p.extra_col = d.d_emb.b[0];
     c.gemm(GEMM_TN, p, 1);
   }
-  STEP(sum_over_groups_to_cols(da0E, PP, T, Hm, d.d_emb.W[0], L + T, L, s1));            // dW0[:, L:]
+  STEP(sum_over_groups_to_cols(da0E, PP, T, Tc, w.plan.tpos, Hm, d.d_emb.W[0], L + T, L, s1));            // dW0[:, L:]
   c.gemm(GEMM_NN, gp(da0E, Hm, d.emb.W[0], L + T, w.dmask_enc, L, PT, L, Hm));            // d mask via encoder input
   if (c.rc) return c.rc;
   STEP(mask_bwd(d.q_mask_logits, d.p_mask_probs, d.temperature, w.mask, w.soft, w.dmaskME, w.dmask_enc, w.cp.coefT,
-                d.d_q_mask_logits, PP, P, T, L, s));
+                d.d_q_mask_logits, PP, P, T, Tc, w.plan.tpos, L, s));
   c.after(0, 1);
   c.after(0, 2);
   if (c.rc) return c.rc;

@@ -37,6 +37,16 @@ class TensorPerturbationDataset:
     def get_dosage_obs_per_dim(self):
         return self.D_obs_per_dim
 
+    def max_dosages_per_cell(self) -> int:
+        """Largest number of non-zero dosages any cell of this data set carries (Norman: 2, Replogle: 1).
+        The fused step sizes its per-cell dosage lists and its compact treatment axis with it."""
+        if getattr(self, "_max_dosages", None) is None:
+            m = 0
+            for i in range(0, self.D.shape[0], 1 << 16):
+                m = max(m, int((self.D[i:i + (1 << 16)] != 0).sum(1).max().item()))
+            self._max_dosages = max(m, 1)
+        return self._max_dosages
+
     def get_qc_obs_per_dim(self):
         return self.qc_obs_per_dim
 

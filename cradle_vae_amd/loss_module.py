@@ -46,6 +46,9 @@ class PerturbationPlatedELBOLossModule(torch.nn.Module):
         self.alpha = alpha
         self.beta = beta
         self.step = "auto"  # 'auto' | 'fused' | 'modular'
+        # upper bound of non-zero dosages per cell the fused step plans for (its kmax); data sets know the
+        # true value (data.TensorPerturbationDataset.max_dosages_per_cell), trainer.fit copies it here
+        self.max_dosages_per_cell = 8
         self._fused = None
 
     # ------------------------------------------------------------------ forward (6-tuple)
@@ -90,10 +93,10 @@ class PerturbationPlatedELBOLossModule(torch.nn.Module):
         return ok
 
     def _fused_step(self):
-        if self._fused is None:
+        if self._fused is None or self._fused.kmax != int(self.max_dosages_per_cell):
             from . import step as step_mod
 
-            self._fused = step_mod.FusedElboStep(self)
+            self._fused = step_mod.FusedElboStep(self, kmax=int(self.max_dosages_per_cell))
         return self._fused
 
     def _loss_modular(self, X, D, D_obs_counts, qc, qc_obs_counts, cfX, condition_values, n_particles, noise,

@@ -140,6 +140,11 @@ def fit(module, train_loader, val_loader=None, *, max_epochs: int = 1, max_steps
     if getattr(module, "use_scheduler", False):
         raise NotImplementedError("use_scheduler=True (SGD + CyclicLR) is never enabled by the reference's entry "
                                   "points (train_norman.py:82); drive configure_optimizers() yourself for it")
+    # the data set knows how many dosages a cell can carry: lets the fused step compact its treatment axis
+    kmax = [ld.dataset.max_dosages_per_cell() for ld in (train_loader, val_loader)
+            if hasattr(getattr(ld, "dataset", None), "max_dosages_per_cell")]
+    if kmax and hasattr(module.loss_module, "max_dosages_per_cell"):
+        module.loss_module.max_dosages_per_cell = max(kmax)
     stepper = TrainStep(module.loss_module, lr=module.lr, weight_decay=module.weight_decay,
                         gradient_clip_norm=gradient_clip_val, world_size=world, seed=seed)
     history, steps = [], 0

@@ -32,8 +32,11 @@ def test_fused_step_matches_reference(name):
     check_against_golden(case, loss, metrics, grads)
 
 
-def test_fused_equals_modular_at_replogle_like_shape():
-    """T > N, L = 100, two-layer-free encoder: sizes the golden fixtures do not reach."""
+@pytest.mark.parametrize("kmax", [8, 2])
+def test_fused_equals_modular_at_replogle_like_shape(kmax):
+    """T > N, L = 100, two-layer-free encoder: sizes the golden fixtures do not reach.  kmax=2 (the
+    data set's true bound) makes N*kmax < T, i.e. the step runs q(M), q(E|M) on the compact axis of
+    treatments present in the batch; kmax=8 keeps the full axis."""
     import dataclasses
 
     from cradle_vae_amd import synthetic as syn
@@ -52,7 +55,9 @@ def test_fused_equals_modular_at_replogle_like_shape():
     case = dict(cfg=cfg, params={k: v.to(DEV) for k, v in params.items()}, batch=b,
                 noise=syn.make_noise(shape, 1, DEV), cf_noise=syn.make_noise(shape, 2, DEV))
     lm = build_loss_module(case)
+    lm.max_dosages_per_cell = kmax
     loss_f, met_f, g_f = run_fused(lm, case)
+    assert lm._fused.desc.kmax == kmax and (lm._fused.desc.N * kmax < lm._fused.desc.T) == (kmax == 2)
     g_f = {k: v.clone() for k, v in g_f.items()}
     lm.step = "modular"
     for p in lm.parameters():
@@ -69,6 +74,32 @@ def test_fused_equals_modular_at_replogle_like_shape():
         ref = p.grad
         err = float((g_f[k] - ref).abs().max()) / max(float(ref.abs().max()), 1e-8)
         assert err < 2e-3, (k, err)
+
+
+def test_compact_axis_overflow_is_reported():
+    """More non-zero dosages in a cell than the declared bound: the step must say so, not mis-score."""
+    import dataclasses
+
+    from cradle_vae_amd import hip
+    from cradle_vae_amd import synthetic as syn
+    from oracle import cradle_oracle as co
+
+    shape = dataclasses.replace(syn.TINY, n_cells=4, n_treatments=12)
+    b = syn.make_batch(shape, seed=3, device=DEV)
+    b["D"][0, :3] = 1.0  # three dosages in one cell
+    cfg = dict(
+        n_latent=shape.n_latent, n_treatments=shape.n_treatments, n_phenos=shape.n_phenos, n_qc=1,
+        decoder_n_layers=1, decoder_n_hidden=8, basal_encoder_n_layers=1, basal_encoder_n_hidden=8,
+        embedding_encoder_n_layers=2, embedding_encoder_n_hidden=8, mask_prior_prob=shape.mask_prior_prob,
+        embedding_prior_scale=1.0, beta=shape.beta, alpha=None, n_particles=shape.n_particles)
+    params = co.init_params(**{k: cfg[k] for k in cfg if k not in ("beta", "alpha", "n_particles")},
+                            log_x_mean=b["log_x_mean"].cpu(), log_x_std=b["log_x_std"].cpu(), seed=1)
+    case = dict(cfg=cfg, params={k: v.to(DEV) for k, v in params.items()}, batch=b,
+                noise=syn.make_noise(shape, 1, DEV), cf_noise=syn.make_noise(shape, 2, DEV))
+    lm = build_loss_module(case)
+    lm.max_dosages_per_cell = 2
+    with pytest.raises(hip.CradleHipError, match="kmax"):
+        run_fused(lm, case)
 
 
 def test_forward_only_matches_training_forward():
