@@ -342,17 +342,18 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
   };
   auto tiles = [&](int tm_, int tn_) { return tiles_ws(2, tm_, tn_); };
   // Heuristics from tools/tune_gemm.py sweeps on MI355X at the ELBO step's shapes:
-  //  * 64x64 tiles (four waves, one 32x32 MFMA tile each, BK 16) win everywhere below ~1000 tiles of
-  //    128x128, because a few hundred large tiles leave whole rounds of CUs idle; long-K problems
-  //    are split along K until ~2048 workgroups are in flight, never below 16 K-steps per split;
+  //  * 64x64 tiles (four waves, one 32x32 MFMA tile each, BK 16) win at every size tried, up to
+  //    10240 x 8000 x 400 (110 TFLOP/s = 87 % of the fp32 matrix peak at the ~1.93 GHz the chip holds
+  //    under MFMA load); 128x128 tiles (kept for tuning runs) are 5-35 % slower -- a few hundred
+  //    large tiles leave whole rounds of CUs idle.  Long-K problems are split along K until ~2048
+  //    workgroups are in flight, never below 16 K-steps per split;
   //  * small problems (up to ~600 tiles of 64x64 and ~5 GFLOP: the embedding / qc encoders, the
   //    hidden layers, most weight gradients) run 15-45 % faster on 32x32 tiles whose four waves
   //    split each 32-wide K step between them: 4x the workgroups and a quarter of the MFMA
   //    chain per wave; split along K towards ~768 workgroups, at least 8 K-steps per split.
   int ws = 2, tm = 1, tn = 1, bk = 16, depth = 2, wk = 1;
   const double flops = 2.0 * p.M * (double)Np * p.K;
-  if (tiles(2, 2) >= 1024) { tm = 2; tn = 2; }
-  else if (tiles(1, 1) <= 600 && flops <= 5e9) { ws = 1; bk = 32; wk = 4; }
+  if (tiles(1, 1) <= 600 && flops <= 5e9) { ws = 1; bk = 32; wk = 4; }
   if (g_tune_tm > 0) { ws = g_tune_ws; tm = g_tune_tm; tn = g_tune_tn; bk = g_tune_bk; depth = g_tune_depth; wk = g_tune_wk; }
   const int64_t ntiles = tiles_ws(ws, tm, tn);
   const int k_tiles = (p.K + bk - 1) / bk;

@@ -35,8 +35,27 @@ shapes = [
     (ops.NT, 1050, 400, 200, "emb l0 fwd"), (ops.NN, 1050, 200, 400, "emb dmask"), (ops.TN, 400, 200, 1050, "emb l0 wgrad"),
     (ops.NT, 5, 400, 200, "wq fwd"),
 ]
-if len(sys.argv) > 1:
-    shapes = [s for s in shapes if any(a in s[4] for a in sys.argv[1:])]
+replogle = [  # N=512, P=5, G=8000, L=100, He=200, Hd=Hm=400, 1024 treatment slots
+    (ops.NT, 2560, 8000, 400, "dec out fwd"), (ops.NN, 2560, 400, 8000, "dec out dgrad"),
+    (ops.TN, 8000, 400, 2560, "dec out wgrad"), (ops.NT, 1024, 200, 8000, "xW fwd"),
+    (ops.TN, 200, 8000, 1024, "xW wgrad"), (ops.NT, 7680, 200, 200, "enc heads fwd"),
+    (ops.NN, 7680, 200, 200, "enc heads dgrad"), (ops.TN, 200, 200, 7680, "enc heads wgrad"),
+    (ops.NT, 10240, 400, 400, "emb fwd"), (ops.NN, 10240, 400, 400, "emb dgrad"), (ops.TN, 400, 400, 10240, "emb wgrad"),
+    (ops.NT, 10240, 400, 100, "emb l0 fwd"), (ops.NT, 10240, 200, 400, "emb heads fwd"),
+    (ops.NN, 10240, 100, 400, "emb dmask"), (ops.TN, 400, 100, 10240, "emb l0 wgrad"),
+]
+huge = [  # batches of 1024 / 2048 cells at G = 8000
+    (ops.NT, 5120, 8000, 400, "dec out fwd 1k"), (ops.NN, 5120, 400, 8000, "dec out dgrad 1k"),
+    (ops.TN, 8000, 400, 5120, "dec out wgrad 1k"), (ops.NT, 10240, 8000, 400, "dec out fwd 2k"),
+    (ops.NN, 10240, 400, 8000, "dec out dgrad 2k"), (ops.TN, 8000, 400, 10240, "dec out wgrad 2k"),
+]
+args = sys.argv[1:]
+if args and args[0] == "--huge":
+    shapes, args = huge, args[1:]
+if args and args[0] == "--replogle":
+    shapes, args = replogle, args[1:]
+if args:
+    shapes = [s for s in shapes if any(a in s[4] for a in args)]
 cfgs = [(2, 2, 16, 2, 1), (1, 1, 16, 2, 1), (1, 1, 16, 4, 1), (1, 1, 32, 2, 1), (1, 1, 32, 2, 2), (1, 1, 32, 4, 2), (1, 2, 32, 2, 2), (2, 2, 32, 2, 2),
         (1, 1, 32, 2, 4), (1, 1, 32, 4, 4), (1, 1, 64, 2, 4), (1, 2, 32, 2, 4), (2, 2, 32, 2, 4)]
 splits = [1, 2, 4, 8, 16]
