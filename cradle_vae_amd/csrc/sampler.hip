@@ -9,8 +9,17 @@
 // particles of that condition and keeps the running sums in registers, so the (P, T, G) sample
 // tensor of the reference is never materialised and the sum over particles is deterministic.
 // Random numbers: Philox4x32-10 keyed by (seed, stream), counter = (gene, row, draw index): the
-// result does not depend on the launch geometry.  (Bit-parity with torch's generator is
+// draws do not depend on the launch geometry.  (Bit-parity with torch's generator is
 // impossible by construction; parity tests use sampler = MEAN, moments tests the real sampler.)
+//
+// Two exact samplers of the same distribution.  Marginally x ~ NegBinomial(c, p = rate/(1+rate)):
+//   * rate >= 1/4 (mean <= 4c: almost every gene of a count matrix): inversion by sequential
+//     search from pmf(0) = p^c with pmf(k+1) = pmf(k) (k+c)/(k+1) / (1+rate) -- one uniform, one
+//     log/exp pair, 1 + x iterations; four genes share one Philox call;
+//   * otherwise the Gamma -> Poisson composition the reference's sampler performs.
+// With workspace, the particles of a condition are split over gridDim.y workgroups whose partial
+// sums are added in a fixed order by a second kernel (a single workgroup per condition leaves the
+// chip almost empty: ~240 conditions per launch).
 #include "common.h"
 #include "nb_math.h"
 
@@ -95,6 +104,35 @@ __device__ float sample_poisson(float lam, const Philox& ph, uint32_t gene, uint
   return floorf(lam);
 }
 
+// The Gamma -> Poisson composition (pyro GammaPoisson.sample).  Not inlined: it is the rare branch
+// of the kernel's gene loop, which must stay small enough to unroll (v[], c[] live in registers).
+__device__ __noinline__ float sample_gamma_poisson(float c, float rate, Philox ph, uint32_t gene, uint32_t row) {
+  uint32_t draw = 0;
+  const float lam = sample_gamma(c, ph, gene, row, draw) / rate;
+  return sample_poisson(lam, ph, gene, row, draw);
+}
+
+// NegBinomial(c, rate) by inversion; requires rate >= kInvRateMin so that the geometric tail
+// (1+rate)^-k is below fp32 resolution long before the iteration cap.
+constexpr float kInvRateMin = 0.25f;
+__device__ __forceinline__ float sample_nb_inversion(float c, float rate, float u) {
+  const float y = __frcp_rn(rate);  // 1/rate in (0, 4]
+  // log1p(y): series below 0.03 (log(1+y) would round 1+y first), fast log above
+  const float l1p = y < 0.03f ? y * (1.0f - y * (0.5f - y * (1.0f / 3.0f))) : __logf(1.0f + y);
+  float pk = __expf(-c * l1p);  // pmf(0) = (rate/(1+rate))^c
+  float cdf = pk, k = 0.f;
+  if (u > cdf) {
+    const float q = y * __frcp_rn(1.0f + y);  // 1/(1+rate)
+    // stop once the increments no longer move the cdf: u is beyond what fp32 resolves
+    while (u > cdf && pk > 1e-9f && k < 512.f) {
+      pk *= (k + c) * q * __frcp_rn(k + 1.0f);
+      k += 1.0f;
+      cdf += pk;
+    }
+  }
+  return k;
+}
+
 enum { SAMPLER_NB = 0, SAMPLER_MEAN = 1 };
 enum { METHOD_MEAN = 0, METHOD_PERTURBSEQ = 1 };
 
@@ -105,7 +143,7 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
                                                                    const float* __restrict__ gene_consts, float* __restrict__ sums,
                                                                    float* __restrict__ samples, int P, int C, int G, int method,
                                                                    int sampler, uint32_t seed_lo, uint32_t seed_hi,
-                                                                   uint32_t row_offset) {
+                                                                   uint32_t row_offset, float* __restrict__ partials) {
   __shared__ float2 red[6][4];
   const int t = blockIdx.x, tid = threadIdx.x;
   const int G4 = G >> 2;
@@ -118,10 +156,11 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
     c[j] = k < G4 ? reinterpret_cast<const float4*>(gene_consts)[k] : make_float4(1.f, 1.f, 1.f, 1.f);
     acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int p = 0; p < P; ++p) {
+  int it = 0;
+  for (int p = blockIdx.y; p < P; p += gridDim.y, ++it) {
     const int64_t r = (int64_t)p * C + t;
     const float4* L4 = reinterpret_cast<const float4*>(logits + r * ld);
-    float2* slot = red[(p & 1) * 3];
+    float2* slot = red[(it & 1) * 3];
     float4 v[VPT];
     float mx = -INFINITY;
 #pragma unroll
@@ -148,17 +187,19 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
       if (k < G4) {
         float* e = reinterpret_cast<float*>(&v[j]);
         const float* cc = reinterpret_cast<const float*>(&c[j]);
+        uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
+        if (sampler == SAMPLER_NB) u4 = ph((uint32_t)k, row, 0u, 5u);  // one uniform per gene of this float4
+        const uint32_t ur[4] = {u4.x, u4.y, u4.z, u4.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float rate = fmaxf(cc[q] / (e[q] * mu_scale + kMuEps), kRateMin);
           float x;
           if (sampler == SAMPLER_MEAN) {
             x = cc[q] / rate;
+          } else if (rate >= kInvRateMin) {
+            x = sample_nb_inversion(cc[q], rate, u01(ur[q]));
           } else {
-            uint32_t draw = 0;
-            const uint32_t gene = (uint32_t)(k * 4 + q);
-            const float lam = sample_gamma(cc[q], ph, gene, row, draw) / rate;
-            x = sample_poisson(lam, ph, gene, row, draw);
+            x = sample_gamma_poisson(cc[q], rate, ph, (uint32_t)(k * 4 + q), row);
           }
           e[q] = x;
           xs += x;
@@ -181,6 +222,15 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
       }
     }
   }
+  if (partials) {  // this workgroup's share of the particles; summed by partial_sums_kernel
+    float4* P4 = reinterpret_cast<float4*>(partials + ((int64_t)blockIdx.y * C + t) * G);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int k = j * 256 + tid;
+      if (k < G4) P4[k] = acc[j];
+    }
+    return;
+  }
   float4* S4 = reinterpret_cast<float4*>(sums + (int64_t)t * G);
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
@@ -193,30 +243,67 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
   }
 }
 
+// sums[i] += partials[0][i] + partials[1][i] + ... (fixed order), i over C*G in float4 steps
+__global__ __launch_bounds__(256) void partial_sums_kernel(const float* __restrict__ partials, float* __restrict__ sums,
+                                                           int64_t n4, int splits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = reinterpret_cast<const float4*>(partials)[i];
+  for (int s = 1; s < splits; ++s) {
+    const float4 b = reinterpret_cast<const float4*>(partials)[(int64_t)s * n4 + i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  float4 o = reinterpret_cast<float4*>(sums)[i];
+  o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+  reinterpret_cast<float4*>(sums)[i] = o;
+}
+
 }  // namespace cradle
 
 using namespace cradle;
 
 extern "C" {
 
+static int particle_splits(int P, int C) {
+  // ~2048 workgroups per launch, at least 4 particles per workgroup
+  int s = (2048 + C - 1) / C;
+  if (s > P / 4) s = P / 4;
+  return s < 1 ? 1 : s;
+}
+
+// Floats of workspace that let cradle_nb_sample_accumulate_ws split the particles of every condition
+// over several workgroups (0: the launch already fills the chip).
+int64_t cradle_nb_sample_workspace_floats(int P, int C, int G) {
+  if (P <= 0 || C <= 0 || G <= 0) return 0;
+  const int s = particle_splits(P, C);
+  return s > 1 ? (int64_t)s * C * G : 0;
+}
+
 // sums (C, G) += sum over the P particles of transform(x[p, t, :]), x ~ GammaPoisson(c, rate(logits)).
 // samples: optional (P*C, G) output of the raw draws (predictor.sample_observations), or NULL.
 // lib: (1) or (C) library sizes.  method: 0 raw counts, 1 "perturbseq".  sampler: 0 NB draw, 1 its mean.
-int cradle_nb_sample_accumulate(const float* logits, int64_t ld_logits, const float* library, int library_n,
-                                const float* gene_consts, float* sums, float* samples, int P, int C, int G, int method,
-                                int sampler, uint64_t seed, uint32_t row_offset, hipStream_t stream) {
+// workspace: optional scratch of cradle_nb_sample_workspace_floats(P, C, G) floats (16-byte aligned);
+// NULL or too small: one workgroup per condition walks all its particles.
+int cradle_nb_sample_accumulate_ws(const float* logits, int64_t ld_logits, const float* library, int library_n,
+                                   const float* gene_consts, float* sums, float* samples, int P, int C, int G, int method,
+                                   int sampler, uint64_t seed, uint32_t row_offset, float* workspace,
+                                   int64_t workspace_floats, hipStream_t stream) {
   CRADLE_CHECK_ARG(logits && library && gene_consts && sums && P > 0 && C > 0 && G > 0, "nb_sample: bad arguments");
   CRADLE_CHECK_ARG(G % 4 == 0 && ld_logits % 4 == 0 && ld_logits >= G, "nb_sample: G and ld must be multiples of 4");
   CRADLE_CHECK_ARG((uintptr_t)logits % 16 == 0 && (uintptr_t)sums % 16 == 0 && (uintptr_t)gene_consts % 16 == 0 &&
-                       (uintptr_t)samples % 16 == 0,
+                       (uintptr_t)samples % 16 == 0 && (uintptr_t)workspace % 16 == 0,
                    "nb_sample: pointers must be 16-byte aligned");
   CRADLE_CHECK_ARG(library_n == 1 || library_n == C, "nb_sample: library has %d entries, expected 1 or %d", library_n, C);
   CRADLE_CHECK_ARG(method >= 0 && method <= 1 && sampler >= 0 && sampler <= 1, "nb_sample: bad method/sampler");
+  CRADLE_CHECK_ARG(C <= 65535 * 64, "nb_sample: too many conditions per launch");
   const int G4 = G / 4;
   const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
-#define CRADLE_SAMPLE_LAUNCH(VPT)                                                                              \
-  hipLaunchKernelGGL((nb_sample_accumulate_kernel<VPT>), dim3(C), dim3(256), 0, stream, logits, ld_logits, library, \
-                     library_n, gene_consts, sums, samples, P, C, G, method, sampler, lo, hi, row_offset)
+  int splits = workspace ? particle_splits(P, C) : 1;
+  while (splits > 1 && (int64_t)splits * C * G > workspace_floats) --splits;
+  float* partials = splits > 1 ? workspace : nullptr;
+#define CRADLE_SAMPLE_LAUNCH(VPT)                                                                                      \
+  hipLaunchKernelGGL((nb_sample_accumulate_kernel<VPT>), dim3(C, splits), dim3(256), 0, stream, logits, ld_logits, library, \
+                     library_n, gene_consts, sums, samples, P, C, G, method, sampler, lo, hi, row_offset, partials)
   if (G4 <= 256) CRADLE_SAMPLE_LAUNCH(1);
   else if (G4 <= 512) CRADLE_SAMPLE_LAUNCH(2);
   else if (G4 <= 1024) CRADLE_SAMPLE_LAUNCH(4);
@@ -229,7 +316,19 @@ int cradle_nb_sample_accumulate(const float* logits, int64_t ld_logits, const fl
   }
 #undef CRADLE_SAMPLE_LAUNCH
   CRADLE_CHECK_LAUNCH("nb_sample_accumulate_kernel");
+  if (partials) {
+    const int64_t n4 = (int64_t)C * G4;
+    hipLaunchKernelGGL(partial_sums_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, partials, sums, n4, splits);
+    CRADLE_CHECK_LAUNCH("partial_sums_kernel");
+  }
   return CRADLE_OK;
+}
+
+int cradle_nb_sample_accumulate(const float* logits, int64_t ld_logits, const float* library, int library_n,
+                                const float* gene_consts, float* sums, float* samples, int P, int C, int G, int method,
+                                int sampler, uint64_t seed, uint32_t row_offset, hipStream_t stream) {
+  return cradle_nb_sample_accumulate_ws(logits, ld_logits, library, library_n, gene_consts, sums, samples, P, C, G, method,
+                                        sampler, seed, row_offset, nullptr, 0, stream);
 }
 
 }  // extern "C"

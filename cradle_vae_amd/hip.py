@@ -55,6 +55,12 @@ PROTOTYPES = {
          ctypes.c_float, ctypes.c_float, i32, ctypes.c_float, ctypes.c_float, c_float_p, c_stream],
     ),
     "cradle_adam_workspace_floats": (i64, []),
+    "cradle_nb_sample_accumulate_ws": (
+        i32,
+        [c_float_p, i64, c_float_p, i32, c_float_p, c_float_p, c_float_p, i32, i32, i32, i32, i32, ctypes.c_uint64,
+         ctypes.c_uint32, c_float_p, i64, c_stream],
+    ),
+    "cradle_nb_sample_workspace_floats": (i64, [i32, i32, i32]),
     "cradle_nb_sample_accumulate": (
         i32,
         [c_float_p, i64, c_float_p, i32, c_float_p, c_float_p, c_float_p, i32, i32, i32, i32, i32, ctypes.c_uint64,

@@ -114,14 +114,29 @@ def nb_sample_accumulate(
     if sums.shape != (C, G):
         raise hip.CradleHipError(f"nb_sample: sums has shape {tuple(sums.shape)}, expected {(C, G)}")
     samples = torch.empty((P * C, G), device=logits.device, dtype=torch.float32) if return_samples else None
+    lib_ = hip.load()
+    need = lib_.cradle_nb_sample_workspace_floats(P, C, G)
+    ws = _sample_workspace(logits.device, need) if need > 0 else None
     hip.check(
-        hip.load().cradle_nb_sample_accumulate(
+        lib_.cradle_nb_sample_accumulate_ws(
             hip.ptr(logits), logits.stride(0), hip.ptr(lib), lib.numel(), hip.ptr(gene_consts), hip.ptr(sums),
             hip.ptr(samples), P, C, G, METHODS[method], SAMPLERS[sampler], seed & (2**64 - 1), row_offset & 0xFFFFFFFF,
-            hip.stream()),
+            hip.ptr(ws), need if ws is not None else 0, hip.stream()),
         "nb_sample_accumulate",
     )
     return sums, samples
+
+
+_SAMPLE_WS = {}
+
+
+def _sample_workspace(device, floats: int) -> torch.Tensor:
+    """Per-device scratch of the sampler's partial sums, grown on demand (stream-ordered reuse)."""
+    ws = _SAMPLE_WS.get(device)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(floats, device=device, dtype=torch.float32)
+        _SAMPLE_WS[device] = ws
+    return ws
 
 
 NT, NN, TN = 0, 1, 2

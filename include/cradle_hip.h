@@ -222,6 +222,17 @@ int64_t cradle_adam_workspace_floats(void);
 int cradle_nb_sample_accumulate(const float* logits, int64_t ld_logits, const float* library, int library_n,
                                 const float* gene_consts, float* sums, float* samples, int P, int C, int G,
                                 int method, int sampler, uint64_t seed, uint32_t row_offset, cradle_stream_t stream);
+/* Same, with scratch that lets the particles of a condition be split over several workgroups (a launch
+ * holds only a few hundred conditions; the reference loops over perturbations one at a time,
+ * average_treatment_effects.py:150-196).  Partial sums are added in a fixed order: deterministic.
+ * The draw is exact for GammaPoisson(c, rate) either way: NegBinomial inversion where rate >= 1/4,
+ * the Gamma -> Poisson composition otherwise.  workspace: cradle_nb_sample_workspace_floats(P, C, G)
+ * floats, 16-byte aligned, or NULL. */
+int cradle_nb_sample_accumulate_ws(const float* logits, int64_t ld_logits, const float* library, int library_n,
+                                   const float* gene_consts, float* sums, float* samples, int P, int C, int G,
+                                   int method, int sampler, uint64_t seed, uint32_t row_offset, float* workspace,
+                                   int64_t workspace_floats, cradle_stream_t stream);
+int64_t cradle_nb_sample_workspace_floats(int P, int C, int G);
 
 #ifdef __cplusplus
 }

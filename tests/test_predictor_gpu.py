@@ -109,7 +109,14 @@ def test_sampler_moments_and_pmf():
     # the sums output is the sum of the returned draws over particles (exact: integers in fp32)
     assert torch.allclose(sums.double().cpu(), x.sum(0), rtol=1e-6)
     # pmf of a few (condition, gene) cells against scipy's negative binomial (chi-square)
-    for (t, g) in [(0, 0), (1, 7), (2, 33), (0, 63)]:
+    # cells chosen by rate so that both exact samplers are checked on either side of their switch
+    # (NegBinomial inversion for rate >= 1/4, Gamma -> Poisson below): extremes and the two nearest 1/4
+    flat = rate.flatten()
+    above, below = torch.nonzero(flat >= 0.25).flatten(), torch.nonzero(flat < 0.25).flatten()
+    assert len(above) > 10 and len(below) > 10
+    picks = [above[flat[above].argmax()], above[flat[above].argmin()], below[flat[below].argmax()],
+             below[flat[below].argmin()], above[len(above) // 2], below[len(below) // 2]]
+    for (t, g) in [(int(i) // G, int(i) % G) for i in picks]:
         xs = x[:, t, g].numpy().astype(np.int64)
         kmax = int(np.quantile(xs, 0.995)) + 1
         obs = np.bincount(np.minimum(xs, kmax), minlength=kmax + 1).astype(np.float64)
