@@ -23,74 +23,110 @@ __device__ __forceinline__ bool finitef_(float x) { return fabsf(x) <= 3.4028234
 // reference (model.py:118-122, correlated_normal_guide.py:186-188, loss_modules.py:224-232) is
 // evaluated from this plan.  Entry order is (cell, column) ascending, so sums are deterministic.
 // =====================================================================================
-__global__ __launch_bounds__(64) void dosage_rows_kernel(const float* __restrict__ D, int N, int T, int kmax,
-                                                         int* __restrict__ ell_idx, float* __restrict__ ell_val,
-                                                         int* __restrict__ tcount, int* __restrict__ flags) {
-  const int n = blockIdx.x, lane = threadIdx.x;
-  int base = 0;
-  for (int c = 0; c < T; c += 64) {
-    const int t = c + lane;
-    const float v = t < T ? D[(int64_t)n * T + t] : 0.f;
-    const bool nz = v != 0.f;
-    const unsigned long long b = __ballot(nz);
-    const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
-    if (nz) {
-      atomicAdd(&tcount[t], 1);
-      if (pos < kmax) {
-        ell_idx[n * kmax + pos] = t;
-        ell_val[n * kmax + pos] = v;
-      }
+constexpr int kMaxDosages = 64;  // upper bound of kmax (check_desc in step.hip)
+
+// One workgroup per cell.  Non-zeros are rare (<= kmax of T), so the row is streamed with all 256
+// threads, hits are appended to a small LDS list in arrival order and thread 0 sorts the list by
+// treatment afterwards: the ELL row is ascending in t whatever the arrival order was.
+__global__ __launch_bounds__(256) void dosage_rows_kernel(const float* __restrict__ D, int N, int T, int kmax,
+                                                          int* __restrict__ ell_idx, float* __restrict__ ell_val,
+                                                          int* __restrict__ tcount, int* __restrict__ flags) {
+  __shared__ int cnt;
+  __shared__ int idx[kMaxDosages];
+  __shared__ float val[kMaxDosages];
+  const int n = blockIdx.x;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const float* row = D + (int64_t)n * T;
+  auto hit = [&](int t, float v) {
+    atomicAdd(&tcount[t], 1);
+    const int pos = atomicAdd(&cnt, 1);
+    if (pos < kmax) {
+      idx[pos] = t;
+      val[pos] = v;
     }
-    base += __popcll(b);
+  };
+  if ((T & 3) == 0 && ((uintptr_t)D & 15) == 0) {
+    for (int t4 = threadIdx.x; t4 < T / 4; t4 += 256) {
+      const float4 v = reinterpret_cast<const float4*>(row)[t4];
+      if (v.x != 0.f) hit(4 * t4, v.x);
+      if (v.y != 0.f) hit(4 * t4 + 1, v.y);
+      if (v.z != 0.f) hit(4 * t4 + 2, v.z);
+      if (v.w != 0.f) hit(4 * t4 + 3, v.w);
+    }
+  } else {
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float v = row[t];
+      if (v != 0.f) hit(t, v);
+    }
   }
-  for (int k = base + lane; k < kmax; k += 64) {
-    ell_idx[n * kmax + k] = -1;
-    ell_val[n * kmax + k] = 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int m = min(cnt, kmax);
+    for (int i = 1; i < m; ++i) {  // insertion sort by treatment
+      const int ti = idx[i];
+      const float vi = val[i];
+      int j = i - 1;
+      for (; j >= 0 && idx[j] > ti; --j) {
+        idx[j + 1] = idx[j];
+        val[j + 1] = val[j];
+      }
+      idx[j + 1] = ti;
+      val[j + 1] = vi;
+    }
+    if (cnt > kmax) atomicOr(flags, 1);
   }
-  if (lane == 0 && base > kmax) atomicOr(flags, 1);
+  __syncthreads();
+  const int m = min(cnt, kmax);
+  for (int k = threadIdx.x; k < kmax; k += 256) {
+    ell_idx[n * kmax + k] = k < m ? idx[k] : -1;
+    ell_val[n * kmax + k] = k < m ? val[k] : 0.f;
+  }
 }
 
+// Exclusive scans over the treatments in one pass: low word = cells of t (CSC column starts), high
+// word = "t has a cell" (slot of every present treatment, ascending; compact axis only).
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const int* __restrict__ tcount, int T, int* __restrict__ tstart,
                                                            int Tc, int* __restrict__ tmap, int* __restrict__ tpos,
                                                            int* __restrict__ flags) {
-  __shared__ int part[1024];
-  __shared__ int carry;
-  // pass 0: exclusive scan of the counts (CSC column starts); pass 1 (compact axis only): exclusive
-  // scan of "has a cell" -> slot of every present treatment, ascending
-  for (int pass = 0; pass < (tmap ? 2 : 1); ++pass) {
-    if (threadIdx.x == 0) carry = 0;
+  __shared__ unsigned long long wave_tot[16];
+  __shared__ unsigned long long carry;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0ull;
+  __syncthreads();
+  for (int c = 0; c < T; c += 1024) {
+    const int t = c + threadIdx.x;
+    const int cn = t < T ? tcount[t] : 0;
+    const unsigned long long v = (unsigned long long)(unsigned)cn | ((unsigned long long)(cn > 0 ? 1u : 0u) << 32);
+    unsigned long long inc = v;  // inclusive scan within the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long up = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += up;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
-    for (int c = 0; c < T; c += 1024) {
-      const int t = c + threadIdx.x;
-      const int cnt = t < T ? tcount[t] : 0;
-      const int v = pass == 0 ? cnt : (cnt > 0 ? 1 : 0);
-      part[threadIdx.x] = v;
-      __syncthreads();
-      for (int off = 1; off < 1024; off <<= 1) {
-        int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
-      }
-      if (t < T) {
-        const int ex = carry + part[threadIdx.x] - v;
-        if (pass == 0) {
-          tstart[t] = ex;
-        } else if (v && ex < Tc) {
-          tpos[t] = ex;
-          tmap[ex] = t;
+    unsigned long long base = carry;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    const unsigned long long ex = base + inc - v;
+    if (t < T) {
+      tstart[t] = (int)(unsigned)(ex & 0xffffffffull);
+      if (tmap) {
+        const int slot = (int)(ex >> 32);
+        if (cn > 0 && slot < Tc) {
+          tpos[t] = slot;
+          tmap[slot] = t;
         } else {
           tpos[t] = -1;
-          if (v) atomicOr(flags, 1);  // more present treatments than slots: kmax too small
+          if (cn > 0) atomicOr(flags, 1);  // more present treatments than slots: kmax too small
         }
       }
-      __syncthreads();
-      if (threadIdx.x == 1023) carry += part[1023];
-      __syncthreads();
     }
-    if (pass == 0 && threadIdx.x == 0) tstart[T] = carry;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = base + inc;
     __syncthreads();
   }
+  if (threadIdx.x == 0) tstart[T] = (int)(unsigned)(carry & 0xffffffffull);
 }
 
 // One wave per treatment scans the ELL entries in (cell, slot) order, 64 at a time; the ballot
@@ -123,7 +159,7 @@ int build_dosage_plan(const float* D, int N, int T, const DosagePlan& plan, hipS
     cradle_set_error("build_dosage_plan: memset failed: %s", hipGetErrorString(e));
     return CRADLE_ERR_HIP;
   }
-  hipLaunchKernelGGL(dosage_rows_kernel, dim3(N), dim3(64), 0, stream, D, N, T, plan.kmax, plan.ell_idx, plan.ell_val,
+  hipLaunchKernelGGL(dosage_rows_kernel, dim3(N), dim3(256), 0, stream, D, N, T, plan.kmax, plan.ell_idx, plan.ell_val,
                      plan.tcount, plan.flags);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, plan.tcount, T, plan.tstart, plan.Tc, plan.tmap,
                      plan.tpos, plan.flags);
@@ -178,24 +214,6 @@ __global__ __launch_bounds__(256) void cell_prep_kernel(const float* __restrict_
     (void)w;
     for (int p = 0; p < P; ++p) o.grow[(int64_t)p * N + n] = -o.wrec[n] * inv_pn;
   }
-  for (int t = threadIdx.x; t < T; t += 256) {
-    float s = 1.0f / D_obs[t];
-    if (isinf(s)) s = 0.f;
-    const float c = (float)tcount[t] * s;
-    o.cw[t] = c;
-    o.coefT[t] = -c * inv_pn;
-  }
-  for (int j = threadIdx.x; j < Tc; j += 256) {  // the same weights by slot
-    const int t = tmap ? tmap[j] : j;
-    float c = 0.f;
-    if (t >= 0) {
-      float s = 1.0f / D_obs[t];
-      if (isinf(s)) s = 0.f;
-      c = (float)tcount[t] * s;
-    }
-    o.cwc[j] = c;
-    o.coefTc[j] = -c * inv_pn;
-  }
   for (int q = threadIdx.x; q < Q; q += 256) {
     float s = 1.0f / qc_obs[q];
     if (isinf(s)) s = 0.f;
@@ -205,10 +223,35 @@ __global__ __launch_bounds__(256) void cell_prep_kernel(const float* __restrict_
   }
 }
 
+// plate weights of the treatments (loss_modules.py:224-232), by treatment and by slot
+__global__ __launch_bounds__(256) void plate_weights_kernel(const float* __restrict__ D_obs, const int* __restrict__ tcount,
+                                                            int P, int N, int T, CellPrep o, int Tc,
+                                                            const int* __restrict__ tmap) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float inv_pn = 1.0f / ((float)P * (float)N);
+  auto weight = [&](int t) {
+    float s = 1.0f / D_obs[t];
+    if (isinf(s)) s = 0.f;
+    return (float)tcount[t] * s;
+  };
+  if (i < T) {
+    const float c = weight(i);
+    o.cw[i] = c;
+    o.coefT[i] = -c * inv_pn;
+  }
+  if (i < Tc) {
+    const int t = tmap ? tmap[i] : i;
+    const float c = t >= 0 ? weight(t) : 0.f;
+    o.cwc[i] = c;
+    o.coefTc[i] = -c * inv_pn;
+  }
+}
+
 int cell_prep(const float* qc, const float* D_obs, const float* qc_obs, const int* tcount, float alpha_fixed, int P,
               int N, int T, int Q, const CellPrep& out, int* flags, int Tc, const int* tmap, hipStream_t stream) {
   hipLaunchKernelGGL(cell_prep_kernel, dim3(1), dim3(256), 0, stream, qc, D_obs, qc_obs, tcount, alpha_fixed, P, N, T, Q,
                      out, flags, Tc, tmap);
+  hipLaunchKernelGGL(plate_weights_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, D_obs, tcount, P, N, T, out, Tc, tmap);
   CRADLE_CHECK_LAUNCH("cell_prep_kernel");
   return CRADLE_OK;
 }
