@@ -180,10 +180,9 @@ int build_dosage_plan_csc(int N, int T, const DosagePlan& plan, hipStream_t stre
 //   recon = alpha (1-qc) logp_good + (1-alpha) qc logp_bad   (qc in {0,1}: one live variant per cell)
 //   plated terms: sum_n (cond[n,c] != 0)/obs[c] -> cw[c]
 // =====================================================================================
-__global__ __launch_bounds__(256) void cell_prep_kernel(const float* __restrict__ qc, const float* __restrict__ D_obs,
-                                                        const float* __restrict__ qc_obs, const int* __restrict__ tcount,
-                                                        float alpha_fixed, int P, int N, int T, int Q, CellPrep o,
-                                                        int* __restrict__ flags, int Tc, const int* __restrict__ tmap) {
+__global__ __launch_bounds__(256) void cell_prep_kernel(const float* __restrict__ qc, const float* __restrict__ qc_obs,
+                                                        float alpha_fixed, int P, int N, int Q, CellPrep o,
+                                                        int* __restrict__ flags) {
   __shared__ float red[8];
   __shared__ float red2[8];
   float qsum = 0.f, nzc = 0.f;
@@ -209,9 +208,7 @@ __global__ __launch_bounds__(256) void cell_prep_kernel(const float* __restrict_
   __syncthreads();  // o.live written by this block is re-read below
   for (int n = threadIdx.x; n < N; n += 256) {
     const float m = o.live[n];
-    const float w = alpha * (1.0f - m) + (1.0f - alpha) * m;  // exact for m in {0,1}
-    o.wrec[n] = (m != 0.f) ? (1.0f - alpha) * m : alpha * (1.0f - m);
-    (void)w;
+    o.wrec[n] = (m != 0.f) ? (1.0f - alpha) * m : alpha * (1.0f - m);  // exact for m in {0,1}
     for (int p = 0; p < P; ++p) o.grow[(int64_t)p * N + n] = -o.wrec[n] * inv_pn;
   }
   for (int q = threadIdx.x; q < Q; q += 256) {
@@ -249,8 +246,7 @@ __global__ __launch_bounds__(256) void plate_weights_kernel(const float* __restr
 
 int cell_prep(const float* qc, const float* D_obs, const float* qc_obs, const int* tcount, float alpha_fixed, int P,
               int N, int T, int Q, const CellPrep& out, int* flags, int Tc, const int* tmap, hipStream_t stream) {
-  hipLaunchKernelGGL(cell_prep_kernel, dim3(1), dim3(256), 0, stream, qc, D_obs, qc_obs, tcount, alpha_fixed, P, N, T, Q,
-                     out, flags, Tc, tmap);
+  hipLaunchKernelGGL(cell_prep_kernel, dim3(1), dim3(256), 0, stream, qc, qc_obs, alpha_fixed, P, N, Q, out, flags);
   hipLaunchKernelGGL(plate_weights_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, D_obs, tcount, P, N, T, out, Tc, tmap);
   CRADLE_CHECK_LAUNCH("cell_prep_kernel");
   return CRADLE_OK;

@@ -218,3 +218,48 @@ def test_synthetic_data_module_interface():
     assert ate.X.shape == (len(names), 24) and ate.uns["control"] == "non-targeting"
     b = next(iter(dm.train_dataloader()))
     assert set(b) == {"X", "D", "qc", "cfX", "library_size", "idx"} and b["X"].shape == (50, 24)
+
+
+def test_max_dosages_per_cell_reaches_the_loss_module():
+    """The data set's bound on non-zero dosages per cell sizes the fused step's dosage lists and its
+    compact treatment axis; trainer.fit copies it to the loss module (and a changed bound rebuilds
+    the step)."""
+    from cradle_vae_amd.data import TensorPerturbationDataset
+
+    D = torch.zeros(7, 5)
+    D[0, 1] = 1.0
+    D[3, [0, 2, 4]] = torch.tensor([1.0, 0.5, 2.0])
+    ds = TensorPerturbationDataset(X=torch.ones(7, 4), D=D, qc=torch.zeros(7, 1))
+    assert ds.max_dosages_per_cell() == 3
+    empty = TensorPerturbationDataset(X=torch.ones(2, 4), D=torch.zeros(2, 5), qc=torch.zeros(2, 1))
+    assert empty.max_dosages_per_cell() == 1  # all-control data: one (unused) slot per cell
+
+    from cradle_vae_amd import trainer
+
+    class _Loader(list):
+        dataset = ds
+
+    seen = {}
+
+    class _Stop(Exception):
+        pass
+
+    class _LM:
+        max_dosages_per_cell = 8
+
+    class _Module:
+        loss_module = _LM()
+        lr, weight_decay, n_particles, use_scheduler = 1e-3, 0.0, 1, False
+
+    def fake_train_step(lm, **kw):
+        seen["kmax"] = lm.max_dosages_per_cell
+        raise _Stop()
+
+    orig = trainer.TrainStep
+    trainer.TrainStep = fake_train_step
+    try:
+        with pytest.raises(_Stop):
+            trainer.fit(_Module(), _Loader())
+    finally:
+        trainer.TrainStep = orig
+    assert seen["kmax"] == 3
