@@ -1,4 +1,4 @@
-// K10: global-norm gradient clip + Adam in two passes over the flat parameter arena.
+// K10: global-norm gradient clip + Adam in two passes (two launches) over the flat parameter arena.
 //
 // Reference: Lightning's `gradient_clip_val=100` (train_norman.py:96 ->
 // torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6))) followed by
@@ -28,20 +28,19 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
-__global__ __launch_bounds__(256) void norm_finish_kernel(float* __restrict__ ws, int nblocks, float grad_scale) {
-  __shared__ float red[4];
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < nblocks; i += 256) acc += ws[i];
-  acc = block_sum<256>(acc, red);
-  if (threadIdx.x == 0) ws[nblocks] = sqrtf(acc) * fabsf(grad_scale);  // norm of the scaled gradient
-}
-
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                                                    float wd, float bc1, float sqrt_bc2, float max_norm, float grad_scale,
-                                                   const float* __restrict__ norm) {
+                                                   float* __restrict__ ws) {
+  // every workgroup finishes the norm from the kNormBlocks partial sums itself (same order everywhere:
+  // same value), which saves a single-workgroup launch between the two passes
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < kNormBlocks; i += 256) acc += ws[i];
+  const float norm = sqrtf(block_sum<256>(acc, red)) * fabsf(grad_scale);  // norm of the scaled gradient
+  if (blockIdx.x == 0 && threadIdx.x == 0) ws[kNormBlocks] = norm;
   float scale = grad_scale;
-  if (max_norm > 0.f) scale *= fminf(1.0f, max_norm / (norm[0] + 1e-6f));
+  if (max_norm > 0.f) scale *= fminf(1.0f, max_norm / (norm + 1e-6f));
   const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float pi = p[i];
@@ -60,12 +59,11 @@ int adam_step(float* params, const float* grads, float* m, float* v, int64_t n, 
   CRADLE_CHECK_ARG(params && grads && m && v && norm_ws && n > 0 && step >= 1, "adam_step: bad arguments");
   CRADLE_CHECK_ARG((uintptr_t)grads % 16 == 0, "adam_step: grads must be 16-byte aligned");
   hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, stream, grads, n, norm_ws);
-  hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, stream, norm_ws, kNormBlocks, grad_scale);
   const float bc1 = 1.0f - powf(beta1, (float)step);
   const float sqrt_bc2 = sqrtf(1.0f - powf(beta2, (float)step));
   const int blocks = (int)min((int64_t)2048, (n + 255) / 256);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, sqrt_bc2, max_norm, grad_scale, norm_ws + kNormBlocks);
+                     weight_decay, bc1, sqrt_bc2, max_norm, grad_scale, norm_ws);
   CRADLE_CHECK_LAUNCH("adam_step");
   return CRADLE_OK;
 }

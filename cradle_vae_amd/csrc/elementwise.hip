@@ -828,10 +828,10 @@ __global__ __launch_bounds__(1024) void enc_combine_bwd_vq_kernel(const float* _
 }
 
 int enc_combine_bwd(const float* dpre, const float* qc, float* doffW, float* dxW, float* dvq, int P, int N, int Q, int H,
-                    hipStream_t stream) {
+                    hipStream_t stream, hipStream_t vq_stream) {
   hipLaunchKernelGGL(enc_combine_bwd_kernel, dim3(N), dim3(128), 0, stream, dpre, doffW, dxW, P, N, H);
-  hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3((H + 15) / 16, 2 * P * Q), dim3(1024), 0, stream, dpre, qc, dvq, P,
-                     N, Q, H);
+  hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3((H + 15) / 16, 2 * P * Q), dim3(1024), 0, vq_stream, dpre, qc, dvq,
+                     P, N, Q, H);
   CRADLE_CHECK_LAUNCH("enc_combine_bwd");
   return CRADLE_OK;
 }

@@ -57,6 +57,7 @@ int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, floa
                                     void* ev_end, hipStream_t stream);
 }
 namespace cradle {
+int nb_dlogc_reduce(const float* workspace, int rows, int G, float* dlog_c, int accumulate, hipStream_t stream);
 
 // ---- elementwise.hip : plan / per-cell preparation
 struct DosagePlan {
@@ -128,8 +129,9 @@ int scatter_offsets(const DosagePlan& plan, const float* a1, int64_t ld1, const 
                     int64_t ldb1, float* dME, int PP, int P, int N, int T, int L, hipStream_t stream);
 int enc_combine_fwd(const float* xW, const float* offW, const float* vq, const float* bias, const float* qc, float* h,
                     int P, int N, int Q, int H, hipStream_t stream);
+// dvq (the qc-embedding part) is produced on `vq_stream`: its consumers are off the critical path
 int enc_combine_bwd(const float* dpre, const float* qc, float* doffW, float* dxW, float* dvq, int P, int N, int Q, int H,
-                    hipStream_t stream);
+                    hipStream_t stream, hipStream_t vq_stream);
 
 // ---- elementwise.hip : small helpers
 int transpose_cols(const float* W, int64_t ldw, int rows, int col0, int cols, float* out, hipStream_t stream);

@@ -270,6 +270,16 @@ static int check_common(const void* logits, const void* X, const void* lib, cons
 
 using namespace cradle;
 
+namespace cradle {
+// d loss / d log_concentration: column sums of the `rows` = N * particle_split partial rows the rows
+// kernel left in `workspace`.  Separate from the rows launch so that the step can run it beside the backward.
+int nb_dlogc_reduce(const float* workspace, int rows, int G, float* dlog_c, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(colsum_kernel, dim3((G + 15) / 16), dim3(1024), 0, stream, workspace, rows, G, dlog_c, accumulate);
+  CRADLE_CHECK_LAUNCH("colsum_kernel");
+  return CRADLE_OK;
+}
+}  // namespace cradle
+
 extern "C" {
 
 int cradle_nb_gene_consts(const float* log_c, float* gene_consts, int G, hipStream_t stream) {
@@ -312,7 +322,7 @@ int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, floa
                                     void* ev_end, hipStream_t stream) {
   int rc = check_common(logits, X, lib, gene_consts, out, P, N, G, ld_logits, ldx);
   if (rc) return rc;
-  CRADLE_CHECK_ARG(dlogits && grow && dlog_c && workspace, "nb_logprob_fwd_bwd: null pointer argument");
+  CRADLE_CHECK_ARG(dlogits && grow && workspace, "nb_logprob_fwd_bwd: null pointer argument");
   CRADLE_CHECK_ARG(ld_dlogits >= G && ld_dlogits % 4 == 0 && (uintptr_t)dlogits % 16 == 0,
                    "nb_logprob_fwd_bwd: dlogits must be 16-byte aligned with ld >= G, ld %% 4 == 0");
   const int PS = cradle_nb_particle_split(P, N);
@@ -324,10 +334,8 @@ int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, floa
                             P, N, G, PS, stream);
   if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_kernel, dim3((G + 15) / 16), dim3(1024), 0, stream, workspace, N * PS, G, dlog_c,
-                     accumulate_dlog_c);
-  CRADLE_CHECK_LAUNCH("colsum_kernel");
-  return CRADLE_OK;
+  if (!dlog_c) return CRADLE_OK;  // internal callers: the reduction follows on another stream (nb_dlogc_reduce)
+  return cradle::nb_dlogc_reduce(workspace, N * PS, G, dlog_c, accumulate_dlog_c, stream);
 }
 
 int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
@@ -335,6 +343,7 @@ int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlo
                               const float* grow, float* out, float* dlog_c, int accumulate_dlog_c,
                               float* workspace, int64_t workspace_floats, int P, int N, int G,
                               hipStream_t stream) {
+  CRADLE_CHECK_ARG(dlog_c, "nb_logprob_fwd_bwd: null dlog_c");
   return cradle_nb_logprob_fwd_bwd_timed(logits, ld_logits, dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out,
                                          dlog_c, accumulate_dlog_c, workspace, workspace_floats, P, N, G, nullptr,
                                          nullptr, stream);

@@ -507,6 +507,11 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s1));
   c.gemm(GEMM_NT, gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G), 1);  // x Wx^T, X and cfX
 
+  hipEvent_t ev_w0t = nullptr;
+  if (!w.plan.tmap) {  // one-hot block of the embedding encoder's first layer as a (T, Hm) table: weights only
+    STEP(transpose_cols(d.emb.W[0], L + T, Hm, L, T, w.W0tT, s2));
+    ev_w0t = c.record(2);
+  }
   STEP(cradle_nb_gene_consts(d.log_concentration, w.gene_consts, G, s2));
   hipLaunchKernelGGL(fill_kernel, dim3((Q * L + 255) / 256), dim3(256), 0, s2, w.ones_q, (int64_t)Q * L, 1.0f);
   {  // q(qc_E): constant input ones(Q, L)
@@ -527,7 +532,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   if (w.plan.tmap)
     STEP(gather_cols(d.emb.W[0], L + T, Hm, L, Tc, w.plan.tmap, w.W0tT, s));
   else
-    STEP(transpose_cols(d.emb.W[0], L + T, Hm, L, T, w.W0tT, s));
+    c.wait(0, ev_w0t);
   {  // layer 0: LeakyReLU(mask Wm^T + W_onehot[:, t] + b)
     GemmParams p = gp(w.mask, L, d.emb.W[0], L + T, w.yE[0], Hm, PT, Hm, L);
     p.bias = d.emb.b[0]; p.act = 1; p.rowbias = w.W0tT; p.ld_rb = Hm; p.rb_mode = 2; p.rb_n = Tc;
@@ -573,14 +578,20 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
     if (d.ev_k1_end) (void)hipEventRecord((hipEvent_t)d.ev_k1_end, s);
   } else {  // events bracket the rows kernel only (the launch the roofline in bench.py describes)
     STEP(cradle_nb_logprob_fwd_bwd_timed(w.logits, G, w.logits, G, d.X, G, d.library_size, w.gene_consts, w.cp.grow,
-                                         w.recon, d.d_log_concentration, 0, w.nbws, w.nbws_floats, P, N, G,
-                                         d.ev_k1_begin, d.ev_k1_end, s));
+                                         w.recon, nullptr, 0, w.nbws, w.nbws_floats, P, N, G, d.ev_k1_begin,
+                                         d.ev_k1_end, s));
   }
   }  // PH_K1
   if (!(phases & PH_POST)) return CRADLE_OK;
+  // the loss scalars and d log_c are leaves of the graph: stream 2, beside the backward pass
+  c.after(2, 0);
+  if (d.compute_grads) STEP(nb_dlogc_reduce(w.nbws, N * cradle_nb_particle_split(P, N), G, d.d_log_concentration, 0, s2));
   STEP(finalize_loss(w.recon, w.cp.wrec, w.ltz, w.klrow, w.Smask, w.SE, w.Sq, w.cp.cwc, w.cp.cwq, d.beta, P, N, Tc, Q,
-                     d.out, s));
-  if (!d.compute_grads) return CRADLE_OK;
+                     d.out, s2));
+  if (!d.compute_grads) {
+    c.after(0, 2);
+    return c.rc;
+  }
 
   // ================================================================== backward
   // The data-gradient chain runs on stream 0; every weight-gradient GEMM is forked to a side
@@ -594,11 +605,11 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
     p.extra_col = d.d_dec.b[0];
     c.gemm(GEMM_TN, p, 2);
   }
-  STEP(weighted_rowgroup_sum(da0d, w.cp.live, P, N, Hd, w.dwq, s));
-  c.after(2, 0);
+  // the bad-variant shift (per particle) only feeds q(qc_E), whose backward lives on stream 2
+  STEP(weighted_rowgroup_sum(da0d, w.cp.live, P, N, Hd, w.dwq, s2));
   c.gemm(GEMM_TN, gp(w.dwq, Hd, w.qsum, L, d.d_dec.W[0] + 2 * L, 3 * L, Hd, L, P), 2);  // dW0[:, 2L:]
   mark_all(c, d.ev_bucket[0]);  // every decoder gradient has been enqueued
-  c.gemm(GEMM_NN, gp(w.dwq, Hd, Wd0 + 2 * L, 3 * L, w.dq_dec, L, P, L, Hd));            // d qsum
+  c.gemm(GEMM_NN, gp(w.dwq, Hd, Wd0 + 2 * L, 3 * L, w.dq_dec, L, P, L, Hd), 2);         // d qsum
   c.gemm(GEMM_NN, gp(da0d, Hd, Wd0, 3 * L, w.dzoff, 2 * L, PN, 2 * L, Hd));             // [dz | doff]
   if (c.rc) return c.rc;
 
@@ -606,7 +617,8 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   STEP(zhead_bwd(w.headsz, d.eps_z, w.zoff, 2 * L, w.sdz, w.dzoff, 2 * L, w.dheadsz, P, N, L, s));
   const float* dpre = head_trunk_bwd(c, d.enc, d.d_enc, 3 * PN, He, 2 * L, w.dheadsz, w.yz, w.rz, w.Gz, w.daz, 0, 1, 2);
   if (c.rc) return c.rc;
-  STEP(enc_combine_bwd(dpre, d.qc, w.doffW, w.dxW, w.dvq, P, N, Q, He, s));
+  c.after(2, 0);  // dvq on stream 2: it feeds dWqc and q(qc_E) only
+  STEP(enc_combine_bwd(dpre, d.qc, w.doffW, w.dxW, w.dvq, P, N, Q, He, s, s2));
   float* dWenc0 = d.d_enc.W[0];
   c.after(1, 0);
   c.after(2, 0);
@@ -625,11 +637,10 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   c.gemm(GEMM_TN, gp(w.dvq, He, w.qcE, L, dWenc0 + G + L, ldenc, He, L, PP * Q), 2);      // dWqc
   mark_all(c, d.ev_bucket[1]);  // every basal-encoder gradient has been enqueued
   c.gemm(GEMM_NN, gp(w.doffW, He, Wenc0 + G, ldenc, w.doffenc, L, 2 * PN, L, He));        // d offsets via encoder
-  c.gemm(GEMM_NN, gp(w.dvq, He, Wenc0 + G + L, ldenc, w.dq_enc, L, PP * Q, L, He));       // d qc_E via encoder
+  c.gemm(GEMM_NN, gp(w.dvq, He, Wenc0 + G + L, ldenc, w.dq_enc, L, PP * Q, L, He), 2);    // d qc_E via encoder
   if (c.rc) return c.rc;
 
-  // q(qc_E): whole backward on stream 2 (tiny, off the critical path)
-  c.after(2, 0);
+  // q(qc_E): whole backward on stream 2 (tiny, off the critical path; dq_dec and dq_enc were made there)
   STEP(qce_bwd(w.headsq, d.eps_qc_E, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.dq_enc, w.dq_dec, w.cp.coefQ,
                w.dheadsq, PP, P, Q, L, s2));
   const float* da0q = head_trunk_bwd(c, d.qce, d.d_qce, Q, Hm, 2 * L, w.dheadsq, w.yq, w.rq, w.Gq, w.daq, 2, 2, 2);
