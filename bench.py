@@ -192,6 +192,9 @@ def main():
         # region holds no graph capture.
         stepper.fused.k1_events = [] if rank == 0 else None
         stepper.fused.gemm_events = [] if rank == 0 else None
+        # every 4th step of the timed region carries the four timing events (each is a barrier packet
+        # of ~5 us between dependent kernels); the roofline averages over those launches
+        stepper.fused.event_every = 4
 
     def one_step(i):
         return stepper(batch, n_particles=shape.n_particles)
@@ -246,7 +249,7 @@ def main():
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": k1_pmc_traffic(G, N, P),
                 "kernel": "nb_rows_kernel<BWD> (K1 fused fwd+bwd, one decoder variant per launch)",
-                "launch_us": t_k1 * 1e6, "launches_per_step": len(k1) / args.steps,
+                "launch_us": t_k1 * 1e6, "launches_per_step": float(V), "launches_timed": len(k1),
                 "algorithmic_bytes_per_launch": alg_bytes,
             }
         # MFMA side: minimal-form GEMM flops of the step (fwd+bwd = 3x fwd) over the whole

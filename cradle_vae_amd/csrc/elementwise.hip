@@ -683,8 +683,11 @@ __global__ __launch_bounds__(64) void gather_offsets_kernel(const float* __restr
                                                             const float* __restrict__ ell_val, int kmax, float* __restrict__ offA,
                                                             int64_t ldA, float* __restrict__ offB, int64_t ldB, int P, int N,
                                                             int Tc, const int* __restrict__ tpos, int L) {
+  // offB: (2P*N, L) offsets of both guide passes (main rows first), one operand for the encoder GEMMs;
+  // offA: the main pass once more, inside the decoder input [z | offset]
   const int n = blockIdx.x, pp = blockIdx.y;
-  float* out = pp < P ? offA + ((int64_t)pp * N + n) * ldA : offB + ((int64_t)(pp - P) * N + n) * ldB;
+  float* out = offB + ((int64_t)pp * N + n) * ldB;
+  float* out2 = pp < P ? offA + ((int64_t)pp * N + n) * ldA : nullptr;
   const float* tab = ME + (int64_t)pp * Tc * L;
   for (int l = threadIdx.x; l < L; l += 64) {
     float acc = 0.f;
@@ -695,6 +698,7 @@ __global__ __launch_bounds__(64) void gather_offsets_kernel(const float* __restr
       if (slot >= 0) acc = fmaf(ell_val[n * kmax + k], tab[(int64_t)slot * L + l], acc);
     }
     out[l] = acc;
+    if (out2) out2[l] = acc;
   }
 }
 

@@ -191,7 +191,7 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   w.ones_q = a.take<float>((int64_t)Q * L);
   w.xn = a.take<float>(2ll * N * G);
   w.xW = a.take<float>(2ll * N * He);
-  w.offB = a.take<float>(PN * L);
+  w.offB = a.take<float>(2 * PN * L);  // offsets of the main pass, then of the counterfactual pass
   w.zoff = a.take<float>(PN * 2 * L);
   w.offW = a.take<float>(2 * PN * He);
   w.vq = a.take<float>((int64_t)PP * Q * He);
@@ -501,11 +501,12 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   // the gather.  Compact axis: q(M) needs the slot map, so stream 0 waits for the plan's first part.
   STEP(build_dosage_plan(d.D, N, T, w.plan, s1));
   hipEvent_t ev_plan = c.record(1);
+  STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s1));
+  c.gemm(GEMM_NT, gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G), 1);  // x Wx^T, X and cfX
+  // what only the loss weights and the backward scatter need comes after the product the join waits for
   STEP(build_dosage_plan_csc(N, T, w.plan, s1));
   STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, Tc, w.plan.tmap,
                  s1));
-  STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s1));
-  c.gemm(GEMM_NT, gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G), 1);  // x Wx^T, X and cfX
 
   hipEvent_t ev_w0t = nullptr;
   if (!w.plan.tmap) {  // one-hot block of the embedding encoder's first layer as a (T, Hm) table: weights only
@@ -545,8 +546,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
                   s));
   if (!w.plan.tmap) c.wait(0, ev_plan);
   STEP(gather_offsets(w.ME, w.plan, w.zoff + L, 2 * L, w.offB, L, PP, P, N, T, L, s));     // D @ (mask*E)
-  c.gemm(GEMM_NT, gp(w.zoff + L, 2 * L, Wenc0 + G, ldenc, w.offW, He, PN, He, L));         // main pass offsets
-  c.gemm(GEMM_NT, gp(w.offB, L, Wenc0 + G, ldenc, w.offW + (int64_t)PN * He, He, PN, He, L));  // cf pass offsets
+  c.gemm(GEMM_NT, gp(w.offB, L, Wenc0 + G, ldenc, w.offW, He, 2 * PN, He, L));  // offsets . Woff^T, both passes
   c.after(0, 1);
   c.after(0, 2);
   if (c.rc) return c.rc;
@@ -627,13 +627,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
     p.extra_col = d.d_enc.b[0];
     c.gemm(GEMM_TN, p, 1);
   }
-  // dWoff = doffW^T [offA; offB]  (two row blocks of one sum: second call accumulates)
-  c.gemm(GEMM_TN, gp(w.doffW, He, w.zoff + L, 2 * L, dWenc0 + G, ldenc, He, L, PN), 2);
-  {
-    GemmParams p = gp(w.doffW + (int64_t)PN * He, He, w.offB, L, dWenc0 + G, ldenc, He, L, PN);
-    p.beta = 1.0f;
-    c.gemm(GEMM_TN, p, 2);
-  }
+  c.gemm(GEMM_TN, gp(w.doffW, He, w.offB, L, dWenc0 + G, ldenc, He, L, 2 * PN), 2);  // dWoff = doffW^T [offA; offB]
   c.gemm(GEMM_TN, gp(w.dvq, He, w.qcE, L, dWenc0 + G + L, ldenc, He, L, PP * Q), 2);      // dWqc
   mark_all(c, d.ev_bucket[1]);  // every basal-encoder gradient has been enqueued
   c.gemm(GEMM_NN, gp(w.doffW, He, Wenc0 + G, ldenc, w.doffenc, L, 2 * PN, L, He));        // d offsets via encoder

@@ -146,6 +146,9 @@ class FusedElboStep:
         self._states = {}
         self.k1_events = None  # list collecting hip.EventPair around K1 when profiling (bench.py)
         self.gemm_events = None  # same around the decoder output-layer GEMM (the largest of the step)
+        # timed HIP events are barrier packets (~5 us each between dependent kernels): bench.py samples
+        # every `event_every`-th step instead of paying four of them in every step
+        self.event_every = 1
         # hip.EventPair whose two events fire when the decoder / basal-encoder gradients are final
         # (trainer.TrainStep starts their all-reduce while the rest of the backward pass runs)
         self.bucket_events = None
@@ -272,7 +275,8 @@ class FusedElboStep:
         d.beta = float(self.lm.beta)
         d.alpha = -1.0 if self.lm.alpha is None else float(self.lm.alpha)
         d.compute_grads = int(compute_grads)
-        if self.k1_events is not None:
+        sample = self._calls % max(1, self.event_every) == 0
+        if self.k1_events is not None and sample:
             ev = hip.EventPair()
             self.k1_events.append(ev)
             d.ev_k1_begin, d.ev_k1_end = ev.begin, ev.end
@@ -280,7 +284,7 @@ class FusedElboStep:
             d.ev_k1_begin, d.ev_k1_end = None, None
         be = self.bucket_events if (compute_grads and not self.use_graph) else None
         d.ev_bucket[0], d.ev_bucket[1] = (be.begin, be.end) if be is not None else (None, None)
-        if self.gemm_events is not None and not self.use_graph:
+        if self.gemm_events is not None and not self.use_graph and sample:
             ev = hip.EventPair()
             self.gemm_events.append(ev)
             d.ev_gemm_begin, d.ev_gemm_end = ev.begin, ev.end

@@ -60,14 +60,13 @@ class TrainStep:
         parallel.allreduce_mean_grads_(self.params, self.world_size)
 
     def _fused_call(self, batch, n_particles):
-        from . import hip, ops
+        from . import hip
 
         f = self.fused
-        with ops._timed("elbo_step"):
-            out = f.run(
-                X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"],
-                qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
-                n_particles=n_particles, gen_plated=self.gen_plated, gen_local=self.gen_local)
+        out = f.run(
+            X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"],
+            qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
+            n_particles=n_particles, gen_plated=self.gen_plated, gen_local=self.gen_local)
         a = f.arena
         if self.world_size > 1 and self.overlap and not f.use_graph:
             self._bucketed_allreduce(a)
