@@ -1,7 +1,8 @@
 """Two ranks on one GPU (gloo, device tensors staged through the host): the data-parallel training step
 with the bucketed all-reduce that overlaps the backward pass must give exactly the parameters of the
-single all-reduce after the step, identical on both ranks.  (RCCL itself needs >= 2 GPUs; the driver's
-scaling run covers it.)"""
+single all-reduce after the step, identical on both ranks.  RCCL across ranks needs >= 2 GPUs (the driver's
+scaling run covers it); the second test runs the same step over the nccl backend with a one-rank group, which
+exercises the bucket events, the communication stream and RCCL's stream ordering on the one GPU available."""
 import os
 import socket
 
@@ -69,3 +70,46 @@ def test_overlapped_bucket_allreduce_equals_single_allreduce():
     assert torch.equal(b[0][0], b[1][0]), "ranks diverged with the single all-reduce"
     assert torch.equal(a[0][0], b[0][0]), "bucketed and single all-reduce disagree"
     assert a[0][1] != a[1][1]  # different cells per rank: different local losses
+
+
+def _rccl_worker(port, overlap, out):
+    """One rank, backend nccl (= RCCL): the data-parallel step exactly as bench.py --gpus N runs it,
+    on the only GPU a test box has.  world_size 2 is what TrainStep is told, so the bucket events, the
+    communication stream and RCCL's own stream ordering are all exercised; the group itself has one rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CRADLE_OVERLAP_ALLREDUCE="1" if overlap else "0")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        from cradle_vae_amd import synthetic as syn
+        from cradle_vae_amd.trainer import TrainStep
+        from tests import golden_io as gio
+        from tests.test_modular_gpu import build_loss_module
+
+        lm = build_loss_module(gio.load_elbo("mid", torch.float32, "cuda:0"))
+        st = TrainStep(lm, lr=1e-3, world_size=2, seed=7)  # grads are halved in Adam either way
+        assert st.fused is not None and st.overlap == overlap
+        batch = syn.make_batch(syn.MID, seed=50, device="cuda:0")
+        losses = [float(st(batch, n_particles=syn.MID.n_particles)) for _ in range(4)]
+        dist.barrier()
+        torch.cuda.synchronize()
+        out[int(overlap)] = (st.fused.arena.flat.detach().cpu().clone(), losses)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_bucketed_allreduce_single_rank():
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        for overlap in (True, False):
+            p = ctx.Process(target=_rccl_worker, args=(_free_port(), overlap, out))
+            p.start()
+            p.join(timeout=150)
+            if p.is_alive():
+                p.kill()
+            assert p.exitcode == 0, f"RCCL worker (overlap={overlap}) failed"
+        a, b = out[1], out[0]
+    assert torch.equal(a[0], b[0]) and a[1] == b[1], "bucketed and single RCCL all-reduce disagree"
+    assert all(x == x for x in a[1])
