@@ -58,6 +58,7 @@ class cradle_vae_Model(torch.nn.Module):
         condition_values: Optional[Dict[str, torch.Tensor]] = None,
         n_particles: int = 1,
         sample_x: bool = True,
+        live_variant: Optional[torch.Tensor] = None,
     ) -> Tuple[Dict[str, object], Dict[str, torch.Tensor]]:
         """model.py:59-144.  ``sample_x=False`` skips the x_good/x_bad draws (the training loss
         never reads them: loss_modules.py:123-143)."""
@@ -94,6 +95,12 @@ class cradle_vae_Model(torch.nn.Module):
             z_good = torch.cat([samples["z_basal"], off, zero], dim=-1)
             z_bad = torch.cat([samples["z_basal"], off, one], dim=-1)
         lib = cv["library_size"]
+        if live_variant is not None:
+            # qc in {0,1}: a cell's likelihood weight sits on one variant only (loss_modules.py:142,
+            # predictor.py:160-164); decode that one.  live_variant (n,): 0 = good, 1 = bad.
+            sel = live_variant.reshape(1, -1, 1)
+            dists["p_x_live"] = self.decoder(torch.where(sel != 0, z_bad, z_good), lib)
+            return dists, samples
         dists["p_x_good"] = self.decoder(z_good, lib)
         dists["p_x_bad"] = self.decoder(z_bad, lib)
         if sample_x:  # model.py:131-132

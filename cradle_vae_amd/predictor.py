@@ -89,6 +89,9 @@ class PerturbationPlatedPredictor(nn.Module):
         self.guide = guide.eval()
         self.local_variables = local_variables
         self.perturbation_plated_variables = perturbation_plated_variables
+        # IWELBO with qc in {0,1}: score the live decoder variant only (falls back to both by itself)
+        self.live_variant_only = not model.sum_mode
+        self._nonbinary_qc = None
         self.dosage_independent_variables = dosage_independent_variables
 
     def _get_device(self):
@@ -105,11 +108,21 @@ class PerturbationPlatedPredictor(nn.Module):
             X=X, D=D, qc=qc, condition_values=plated, n_particles=n_particles, noise=noise)
         guide_samples = dict(guide_samples)
         guide_samples["library_size"] = batch["library_size"]
-        model_dists, _ = self.model(D=D, qc=qc, condition_values=guide_samples, n_particles=n_particles, sample_x=False)
-        lp_good = model_dists["p_x_good"].log_prob_sum(X)  # (P, n): K1 forward
-        lp_bad = model_dists["p_x_bad"].log_prob_sum(X)
         b_qc = qc.max(dim=1)[0] if qc.shape[1] > 1 else qc[:, 0]  # :160-164
-        terms = (1 - b_qc) * lp_good + b_qc * lp_bad
+        if self.live_variant_only:
+            # (1 - b) lp_good + b lp_bad with b in {0,1} is the live variant's term: one decoder pass and
+            # one K1 launch instead of two; non-binary qc is recorded and the caller recomputes with both
+            model_dists, _ = self.model(D=D, qc=qc, condition_values=guide_samples, n_particles=n_particles,
+                                        sample_x=False, live_variant=b_qc)
+            terms = model_dists["p_x_live"].log_prob_sum(X)  # (P, n): K1 forward
+            bad = ((b_qc != 0) & (b_qc != 1)).any()
+            self._nonbinary_qc = bad if self._nonbinary_qc is None else (self._nonbinary_qc | bad)
+        else:
+            model_dists, _ = self.model(D=D, qc=qc, condition_values=guide_samples, n_particles=n_particles,
+                                        sample_x=False)
+            lp_good = model_dists["p_x_good"].log_prob_sum(X)  # (P, n): K1 forward
+            lp_bad = model_dists["p_x_bad"].log_prob_sum(X)
+            terms = (1 - b_qc) * lp_good + b_qc * lp_bad
         for var_name in self.local_variables:  # :166-177
             v = guide_samples[var_name]
             terms = terms + model_dists[f"p_{var_name}"].log_prob(v).sum(-1) - guide_dists[f"q_{var_name}"].log_prob(v).sum(-1)
@@ -123,6 +136,7 @@ class PerturbationPlatedPredictor(nn.Module):
         if not isinstance(loaders, (list, tuple)):
             loaders = [loaders]
         device = self._get_device()
+        self._nonbinary_qc = None
         _, guide_samples = self.guide(n_particles=n_particles, noise=noise)  # :104
         plated = {k: guide_samples[k] for k in self.perturbation_plated_variables}
         id_list, iwelbo_list = [], []
@@ -131,17 +145,23 @@ class PerturbationPlatedPredictor(nn.Module):
             idx_list_curr = []
             for batch in loader:
                 batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
-                idx_list_curr.append(batch["idx"].detach().cpu().numpy())
+                idx_list_curr.append(batch["idx"].detach())  # moved to the host once, after the loop: no per-batch sync
                 n = batch["X"].shape[0]
                 nz = None
                 if noise is not None and "eps_z" in noise:
                     nz = {"eps_z": noise["eps_z"][:, seen:seen + n].to(device).contiguous()}
                 seen += n
-                iwelbo_list.append(self.iwelbo_batch(batch, plated, n_particles, nz).cpu().numpy())
-            idx_curr = np.concatenate(idx_list_curr)
+                iwelbo_list.append(self.iwelbo_batch(batch, plated, n_particles, nz))
+            idx_curr = torch.cat(idx_list_curr).cpu().numpy() if idx_list_curr else np.zeros((0,), dtype=np.int64)
             id_list.append(loader.dataset.convert_idx_to_ids(idx_curr))
-        return pd.DataFrame(index=np.concatenate(id_list), columns=["IWELBO"],
-                            data=np.concatenate(iwelbo_list).reshape(-1, 1))
+        if self.live_variant_only and self._nonbinary_qc is not None and bool(self._nonbinary_qc):
+            self.live_variant_only = False  # fractional qc weights both variants: score both
+            try:
+                return self.compute_predictive_iwelbo(loaders, n_particles, noise)
+            finally:
+                self.live_variant_only = True
+        values = torch.cat(iwelbo_list).cpu().numpy() if iwelbo_list else np.zeros((0,), dtype=np.float32)
+        return pd.DataFrame(index=np.concatenate(id_list), columns=["IWELBO"], data=values.reshape(-1, 1))
 
     # ------------------------------------------------------------------ sampling
     @torch.no_grad()

@@ -55,6 +55,30 @@ def test_iwelbo_matches_reference():
     np.testing.assert_allclose(df["IWELBO"].to_numpy(), ref, rtol=1e-4, atol=1e-3)
 
 
+def test_iwelbo_live_variant_equals_both_variants_and_falls_back():
+    """With qc in {0,1} the predictor scores one decoder variant per cell; it must equal the
+    reference's two-variant form, and fractional qc must fall back to that form by itself."""
+    case = gio.load_predictor("tiny", torch.float32, DEV)
+    pred = _predictor(case)
+    iw = case["iwelbo"]
+    P, bs = int(iw["n_particles"]), int(iw["batch"])
+    noise = {k[len("noise/"):]: v for k, v in iw.items() if k.startswith("noise/")}
+    assert pred.live_variant_only
+    live = pred.compute_predictive_iwelbo(_Loader(case["batch"], bs), n_particles=P, noise=noise)["IWELBO"].to_numpy()
+    pred.live_variant_only = False
+    both = pred.compute_predictive_iwelbo(_Loader(case["batch"], bs), n_particles=P, noise=noise)["IWELBO"].to_numpy()
+    np.testing.assert_allclose(live, both, rtol=1e-6, atol=1e-5)
+    frac = dict(case["batch"])
+    frac["qc"] = frac["qc"].clone()
+    frac["qc"][0, 0] = 0.25
+    both_frac = pred.compute_predictive_iwelbo(_Loader(frac, bs), n_particles=P, noise=noise)["IWELBO"].to_numpy()
+    pred.live_variant_only = True
+    auto_frac = pred.compute_predictive_iwelbo(_Loader(frac, bs), n_particles=P, noise=noise)["IWELBO"].to_numpy()
+    assert pred.live_variant_only  # restored after the fallback
+    np.testing.assert_allclose(auto_frac, both_frac, rtol=1e-6, atol=1e-5)
+    assert abs(auto_frac[0] - live[0]) > 0  # the fractional cell really scores differently
+
+
 @pytest.mark.parametrize("method", ["mean", "perturbseq"])
 def test_ate_matches_reference(method):
     case = gio.load_predictor("tiny", torch.float32, DEV)
