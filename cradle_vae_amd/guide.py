@@ -96,9 +96,11 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
         condition_values: Optional[Dict[str, torch.Tensor]] = None,
         n_particles: int = 1,
         noise: Optional[Dict[str, torch.Tensor]] = None,
+        need_cf_basal: bool = True,
     ) -> Tuple[Dict[str, object], Dict[str, torch.Tensor]]:
         """correlated_normal_guide.py:102-209.  ``noise`` (keys u_mask, eps_E, eps_qc_E, eps_z)
-        injects the random draws; missing keys are drawn with torch's generator."""
+        injects the random draws; missing keys are drawn with torch's generator.
+        ``need_cf_basal=False`` (inference only) skips ``q_z_cf_basal``, which the predictor never reads."""
         cv = {} if condition_values is None else condition_values
         noise = {} if noise is None else noise
         P = n_particles
@@ -126,12 +128,24 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
         samples["qc_E"] = cv["qc_E"] if "qc_E" in cv else rsample(dists["q_qc_E"], "eps_qc_E")
 
         if X is not None and D is not None and qc is not None:
-            enc_in = self.normalization_module(X).unsqueeze(0).expand(P, -1, -1)
+            xn = self.normalization_module(X)
             latent_offset = torch.matmul(D, samples["mask"] * samples["E"])
             latent_qc_offset = torch.matmul(qc, samples["qc_E"])
             latent_qc_cf_offset = torch.matmul(1 - qc, samples["qc_E"])
-            dists["q_z_cf_basal"] = self.z_basal_encoder(torch.cat([enc_in, latent_offset, latent_qc_cf_offset], dim=-1))
-            dists["q_z_basal"] = self.z_basal_encoder(torch.cat([enc_in, latent_offset, latent_qc_offset], dim=-1))
+            if not torch.is_grad_enabled() and X.is_cuda and latent_offset.dim() == 3:
+                # inference (predictor, validation): x W_x^T once per cell, not once per (particle, cell) row
+                # and per encoder pass -- SURVEY 8a restructuring (ii)
+                enc = self.z_basal_encoder
+                xw = enc.shared_input_part(xn)
+                if need_cf_basal:
+                    dists["q_z_cf_basal"] = enc.forward_shared(
+                        xw, torch.cat([latent_offset, latent_qc_cf_offset], dim=-1))
+                dists["q_z_basal"] = enc.forward_shared(xw, torch.cat([latent_offset, latent_qc_offset], dim=-1))
+            else:
+                enc_in = xn.unsqueeze(0).expand(P, -1, -1)
+                dists["q_z_cf_basal"] = self.z_basal_encoder(
+                    torch.cat([enc_in, latent_offset, latent_qc_cf_offset], dim=-1))
+                dists["q_z_basal"] = self.z_basal_encoder(torch.cat([enc_in, latent_offset, latent_qc_offset], dim=-1))
             samples["z_basal"] = rsample(dists["q_z_basal"], "eps_z")
         if "z_basal" in cv:
             samples["z_basal"] = cv["z_basal"]

@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from . import functional as F_hip
+from . import ops
 from .distributions import LibraryGammaPoisson
 
 LIKELIHOOD_KEY_DTYPE = Literal["normal", "poisson", "library_nb"]
@@ -66,6 +67,30 @@ class GaussianLikelihoodResidualMLP(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.distributions.Normal:
         mean, var = self.mean_var(x)
+        return torch.distributions.Normal(mean, var.sqrt(), validate_args=False)
+
+    # ---- inference form for inputs [x_shared | tail] whose first block is the same for every particle
+    # (the basal encoder reads [log-standardised X | latent offset | qc offset], correlated_normal_guide.py:
+    # 190-204): x W_x^T is computed once per cell and enters the (P*n)-row product of the tail as a
+    # row-bias of the GEMM epilogue.  Equal to forward(cat([x.expand(P), tail])) up to fp reassociation.
+    @torch.no_grad()
+    def shared_input_part(self, x_shared: torch.Tensor) -> torch.Tensor:
+        lin0 = self.mlp.linears()[0]
+        return ops.gemm(ops.NT, x_shared.contiguous(), lin0.weight[:, : x_shared.shape[-1]])  # (n, H)
+
+    @torch.no_grad()
+    def forward_shared(self, xw: torch.Tensor, tail: torch.Tensor) -> torch.distributions.Normal:
+        P, n, r = tail.shape
+        lins = self.mlp.linears()
+        k0 = lins[0].weight.shape[1] - r
+        h = ops.gemm(ops.NT, tail.reshape(P * n, r).contiguous(), lins[0].weight[:, k0:], bias=lins[0].bias, act=True,
+                     rowbias=xw, rowbias_mode=2, rowbias_n=n)
+        for lin in lins[1:]:
+            h = F_hip.linear(h, lin.weight, lin.bias, act=True, residual=h)
+        mean = F_hip.linear(h, self.mean_encoder.weight, self.mean_encoder.bias)
+        var = torch.exp(F_hip.linear(h, self.log_var_encoder.weight, self.log_var_encoder.bias)) + self.var_eps
+        mean = nan_to_num_ref(mean.reshape(P, n, -1))
+        var = nan_to_num_ref(torch.abs(var.reshape(P, n, -1)))
         return torch.distributions.Normal(mean, var.sqrt(), validate_args=False)
 
 

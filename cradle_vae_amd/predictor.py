@@ -105,7 +105,7 @@ class PerturbationPlatedPredictor(nn.Module):
         log p(x|z,...) + log p(z) - log q(z|x,...), the plated variables held at ``plated``."""
         X, D, qc = batch["X"], batch["D"], batch["qc"]
         guide_dists, guide_samples = self.guide(
-            X=X, D=D, qc=qc, condition_values=plated, n_particles=n_particles, noise=noise)
+            X=X, D=D, qc=qc, condition_values=plated, n_particles=n_particles, noise=noise, need_cf_basal=False)
         guide_samples = dict(guide_samples)
         guide_samples["library_size"] = batch["library_size"]
         b_qc = qc.max(dim=1)[0] if qc.shape[1] > 1 else qc[:, 0]  # :160-164
