@@ -21,7 +21,17 @@ namespace cradle {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int KPAD = 4;  // K-major LDS row stride BK+4 floats: conflict-free ds_read_b128
+// K-major tiles [row][BK] are stored without padding; the 16-byte chunk c of row r sits at chunk
+// position c ^ swz(r), swz(r) = (r / (64/BK)) % (BK/4).  A row is BK of the 64 LDS banks, so rows
+// r, r + 64/BK, ... start at the same bank and the XOR spreads their chunks: both the ds_write_b128
+// of the staging store (BK/4 lanes per row) and the ds_read_b128 of a fragment (one chunk of 16
+// consecutive rows) then touch every bank once.  (Padding the rows to BK+4 made the reads
+// conflict-free but not the writes: SQ_LDS_BANK_CONFLICT equalled SQ_ACTIVE_INST_LDS.)
+template <int BK>
+__device__ __forceinline__ int swz_chunk(int r, int c) {
+  constexpr int C = BK / 4, WRAP = 64 / BK > 0 ? 64 / BK : 1;
+  return c ^ ((r / WRAP) % C);
+}
 
 template <bool KMAJOR, int ROWS, int BK, int NT>
 struct TileLoader {
@@ -81,7 +91,7 @@ struct TileLoader {
       const int idx = v * NT + threadIdx.x;
       if (KMAJOR) {
         const int r = idx / (BK / 4), k4 = idx % (BK / 4);
-        *reinterpret_cast<float4*>(lds + r * (BK + KPAD) + k4 * 4) = regs[v];
+        *reinterpret_cast<float4*>(lds + r * BK + swz_chunk<BK>(r, k4) * 4) = regs[v];
       } else {
         const int k = idx / (ROWS / 4), r4 = idx % (ROWS / 4);
         float4 val = regs[v];
@@ -96,12 +106,12 @@ struct TileLoader {
       }
     }
   }
-  static constexpr int lds_floats() { return KMAJOR ? ROWS * (BK + KPAD) : BK * ROWS; }
+  static constexpr int lds_floats() { return BK * ROWS; }
 
   // fragment of 4 k-values (k = ks*8 + 4*h + t, t = 0..3) of tile row `r`
   __device__ static __forceinline__ float4 frag(const float* lds, int r, int ks, int h) {
     if (KMAJOR) {
-      return *reinterpret_cast<const float4*>(lds + r * (BK + KPAD) + ks * 8 + 4 * h);
+      return *reinterpret_cast<const float4*>(lds + r * BK + swz_chunk<BK>(r, ks * 2 + h) * 4);
     } else {
       const float* p = lds + (ks * 8 + 4 * h) * ROWS + r;
       return make_float4(p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]);
