@@ -38,12 +38,15 @@ __global__ __launch_bounds__(256) void dosage_rows_kernel(const float* __restric
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
   const float* row = D + (int64_t)n * T;
+  // tcount counts the entries that are stored: the CSC columns built from it must match the ELL rows
+  // exactly even for a cell with more than kmax dosages (flagged below; the caller raises), or the
+  // backward scatter would walk over unwritten column slots
   auto hit = [&](int t, float v) {
-    atomicAdd(&tcount[t], 1);
     const int pos = atomicAdd(&cnt, 1);
     if (pos < kmax) {
       idx[pos] = t;
       val[pos] = v;
+      atomicAdd(&tcount[t], 1);
     }
   };
   if ((T & 3) == 0 && ((uintptr_t)D & 15) == 0) {
@@ -716,15 +719,18 @@ __global__ __launch_bounds__(256) void scatter_offsets_kernel(const int* __restr
                                                              const float* __restrict__ csc_val, const float* __restrict__ a1,
                                                              int64_t ld1, const float* __restrict__ a2, int64_t ld2,
                                                              const float* __restrict__ b1, int64_t ldb1, float* __restrict__ dME,
-                                                             int P, int N, int Tc, const int* __restrict__ tmap, int L) {
+                                                             int P, int N, int Tc, const int* __restrict__ tmap, int L,
+                                                             int entries) {
   const int j = blockIdx.x, pp = blockIdx.y;
   const int t = tmap ? tmap[j] : j;
-  const int e0 = t >= 0 ? tstart[t] : 0, e1 = t >= 0 ? tstart[t + 1] : 0;  // unused slot: zeros
+  const int e0 = t >= 0 ? tstart[t] : 0;                        // unused slot: zeros
+  const int e1 = t >= 0 ? min(tstart[t + 1], entries) : 0;      // never past the column arrays
   float* out = dME + ((int64_t)pp * Tc + j) * L;
   for (int l = threadIdx.x; l < L; l += blockDim.x) {
     float acc = 0.f;
     for (int e = e0; e < e1; ++e) {
       const int n = csc_cell[e];
+      if ((unsigned)n >= (unsigned)N) continue;  // defensive: an index the plan did not write
       float g;
       if (pp < P) g = a1[((int64_t)pp * N + n) * ld1 + l] + a2[((int64_t)pp * N + n) * ld2 + l];
       else g = b1[((int64_t)(pp - P) * N + n) * ldb1 + l];
@@ -739,7 +745,7 @@ int scatter_offsets(const DosagePlan& plan, const float* a1, int64_t ld1, const 
   const int nt = L <= 64 ? 64 : (L <= 128 ? 128 : 256);  // one pass over the latent columns
   (void)T;
   hipLaunchKernelGGL(scatter_offsets_kernel, dim3(plan.Tc, PP), dim3(nt), 0, stream, plan.tstart, plan.csc_cell, plan.csc_val,
-                     a1, ld1, a2, ld2, b1, ldb1, dME, P, N, plan.Tc, plan.tmap, L);
+                     a1, ld1, a2, ld2, b1, ldb1, dME, P, N, plan.Tc, plan.tmap, L, N * plan.kmax);
   CRADLE_CHECK_LAUNCH("scatter_offsets_kernel");
   return CRADLE_OK;
 }
