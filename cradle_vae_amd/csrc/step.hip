@@ -85,9 +85,10 @@ struct cradle_step_desc {
   void* ev_gemm_end;
   // optional (data-parallel training): events that fire as soon as a bucket of gradients is final,
   // so that the caller can start reducing it while the rest of the backward pass runs.
-  // [0]: decoder gradients (d_dec.*, d_log_concentration); [1]: basal-encoder gradients (d_enc.*).
-  // Everything else is final when the step's work on `stream` is.  NULL = off; ignored when graphed.
-  void* ev_bucket[2];
+  // [0]: decoder output layer (d_dec.W_head/b_head, d_log_concentration); [1]: the other decoder
+  // gradients; [2]: basal-encoder gradients (d_enc.*).  Everything else is final when the step's work
+  // on `stream` is.  NULL = off; ignored when graphed.
+  void* ev_bucket[3];
 };
 
 }  // extern "C"
@@ -383,7 +384,7 @@ void head_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, int Nout, const fl
 // as its da_k exists.  Pass wq == q to keep everything on one stream.
 const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, int M, int H, int Nout,
                             const float* dout, float* const* y, float* const* r, float* const* Gb, float* const* da,
-                            int q, int wq, int wq2) {
+                            int q, int wq, int wq2, void* ev_head_done = nullptr) {
   const int n = m.n_layers;
   int side = wq;
   auto wgrad = [&](GemmParams p) {
@@ -395,6 +396,7 @@ const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_p
     GemmParams p = gp(dout, Nout, y[n - 1], H, g.W_head, H, Nout, H, M);
     p.extra_col = g.b_head;
     wgrad(p);
+    mark_all(c, ev_head_done);  // the output layer's gradients have been enqueued
   }
   int cur = 0;
   {  // G_{n-1} = dout W_head ; da_{n-1} = G_{n-1} * slope(r_{n-1})
@@ -597,7 +599,8 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   // The data-gradient chain runs on stream 0; every weight-gradient GEMM is forked to a side
   // stream as soon as its inputs exist.  All streams are joined before returning.
   // decoder: logits now hold d loss / d logits
-  const float* da0d = head_trunk_bwd(c, d.dec, d.d_dec, PN, Hd, G, w.logits, w.yd, w.rd, w.Gd, w.dad, 0, 1, 2);
+  const float* da0d = head_trunk_bwd(c, d.dec, d.d_dec, PN, Hd, G, w.logits, w.yd, w.rd, w.Gd, w.dad, 0, 1, 2,
+                                     d.ev_bucket[0]);  // (d log_c was enqueued on stream 2 above)
   if (c.rc) return c.rc;
   c.after(2, 0);
   {  // dW0[:, :2L] = da0^T [z | off], db0
@@ -608,7 +611,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   // the bad-variant shift (per particle) only feeds q(qc_E), whose backward lives on stream 2
   STEP(weighted_rowgroup_sum(da0d, w.cp.live, P, N, Hd, w.dwq, s2));
   c.gemm(GEMM_TN, gp(w.dwq, Hd, w.qsum, L, d.d_dec.W[0] + 2 * L, 3 * L, Hd, L, P), 2);  // dW0[:, 2L:]
-  mark_all(c, d.ev_bucket[0]);  // every decoder gradient has been enqueued
+  mark_all(c, d.ev_bucket[1]);  // every decoder gradient has been enqueued
   c.gemm(GEMM_NN, gp(w.dwq, Hd, Wd0 + 2 * L, 3 * L, w.dq_dec, L, P, L, Hd), 2);         // d qsum
   c.gemm(GEMM_NN, gp(da0d, Hd, Wd0, 3 * L, w.dzoff, 2 * L, PN, 2 * L, Hd));             // [dz | doff]
   if (c.rc) return c.rc;
@@ -629,7 +632,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   }
   c.gemm(GEMM_TN, gp(w.doffW, He, w.offB, L, dWenc0 + G, ldenc, He, L, 2 * PN), 2);  // dWoff = doffW^T [offA; offB]
   c.gemm(GEMM_TN, gp(w.dvq, He, w.qcE, L, dWenc0 + G + L, ldenc, He, L, PP * Q), 2);      // dWqc
-  mark_all(c, d.ev_bucket[1]);  // every basal-encoder gradient has been enqueued
+  mark_all(c, d.ev_bucket[2]);  // every basal-encoder gradient has been enqueued
   c.gemm(GEMM_NN, gp(w.doffW, He, Wenc0 + G, ldenc, w.doffenc, L, 2 * PN, L, He));        // d offsets via encoder
   c.gemm(GEMM_NN, gp(w.dvq, He, Wenc0 + G + L, ldenc, w.dq_enc, L, PP * Q, L, He), 2);    // d qc_E via encoder
   if (c.rc) return c.rc;
@@ -800,9 +803,9 @@ int cradle_elbo_step_graphed(const cradle_step_desc* dp, hipStream_t s, int* rec
   if (rc) return rc;
   const cradle_step_desc& d = *dp;
   cradle_step_desc key = d;
-  key.ev_k1_begin = key.ev_k1_end = key.ev_gemm_begin = key.ev_gemm_end = key.ev_bucket[0] = key.ev_bucket[1] = nullptr;
+  key.ev_k1_begin = key.ev_k1_end = key.ev_gemm_begin = key.ev_gemm_end = key.ev_bucket[0] = key.ev_bucket[1] = key.ev_bucket[2] = nullptr;
   cradle_step_desc dg = d;  // events around the GEMM cannot be captured with timing: dropped here
-  dg.ev_gemm_begin = dg.ev_gemm_end = dg.ev_bucket[0] = dg.ev_bucket[1] = nullptr;
+  dg.ev_gemm_begin = dg.ev_gemm_end = dg.ev_bucket[0] = dg.ev_bucket[1] = dg.ev_bucket[2] = nullptr;
   const bool split = d.ev_k1_begin || d.ev_k1_end;
   GraphSlot* sl = nullptr;
   for (auto& cand : gs.slot)

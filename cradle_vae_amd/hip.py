@@ -99,7 +99,7 @@ class StepDesc(ctypes.Structure):
         + [("beta", ctypes.c_float), ("alpha", ctypes.c_float), ("compute_grads", i32)]
         + [("out", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
            ("workspace_bytes", i64), ("ev_k1_begin", ctypes.c_void_p), ("ev_k1_end", ctypes.c_void_p),
-           ("ev_gemm_begin", ctypes.c_void_p), ("ev_gemm_end", ctypes.c_void_p), ("ev_bucket", ctypes.c_void_p * 2)]
+           ("ev_gemm_begin", ctypes.c_void_p), ("ev_gemm_end", ctypes.c_void_p), ("ev_bucket", ctypes.c_void_p * 3)]
     )
 
 

@@ -283,7 +283,8 @@ class FusedElboStep:
         else:
             d.ev_k1_begin, d.ev_k1_end = None, None
         be = self.bucket_events if (compute_grads and not self.use_graph) else None
-        d.ev_bucket[0], d.ev_bucket[1] = (be.begin, be.end) if be is not None else (None, None)
+        for i in range(3):  # bucket_events: two hip.EventPair = (out layer, decoder) and (basal encoder, unused)
+            d.ev_bucket[i] = None if be is None else (be[0].begin, be[0].end, be[1].begin)[i]
         if self.gemm_events is not None and not self.use_graph and sample:
             ev = hip.EventPair()
             self.gemm_events.append(ev)

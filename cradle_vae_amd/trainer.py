@@ -48,7 +48,7 @@ class TrainStep:
             # falls back to one all-reduce of the whole arena after the step)
             self.overlap = world_size > 1 and os.environ.get("CRADLE_OVERLAP_ALLREDUCE", "1") != "0"
             if self.overlap:
-                self.fused.bucket_events = hip.EventPair()
+                self.fused.bucket_events = (hip.EventPair(), hip.EventPair())
                 self.comm_stream = torch.cuda.Stream(device=self.device)
 
     def draw_noise(self, P, N):
@@ -84,20 +84,23 @@ class TrainStep:
         return out[0]
 
     def _bucketed_allreduce(self, a):
-        """Sum of the gradient arena over ranks in three contiguous buckets, in the order the backward
-        pass finishes them (decoder, basal encoder, the rest), on a communication stream that waits for
-        the events the step records: the first two all-reduces run under the remaining backward kernels."""
+        """Sum of the gradient arena over ranks in four contiguous buckets, in the order the backward
+        pass finishes them (decoder output layer, rest of the decoder, basal encoder, the rest), on a
+        communication stream that waits for the events the step records: the first three all-reduces
+        run under the remaining backward kernels."""
         from . import hip
 
         lib = hip.load()
         ev = self.fused.bucket_events
-        o_enc, o_dec = a.offsets["enc.W0"], a.offsets["dec.W0"]
+        o_enc, o_dec, o_out = a.offsets["enc.W0"], a.offsets["dec.W0"], a.offsets["dec.Wh"]
         cur = torch.cuda.current_stream()
         with torch.cuda.stream(self.comm_stream):
             cs = self.comm_stream.cuda_stream
-            hip.check(lib.cradle_stream_wait_event(cs, ev.begin), "stream_wait_event")
-            parallel._all_reduce(a.grad[o_dec:])
-            hip.check(lib.cradle_stream_wait_event(cs, ev.end), "stream_wait_event")
+            hip.check(lib.cradle_stream_wait_event(cs, ev[0].begin), "stream_wait_event")
+            parallel._all_reduce(a.grad[o_out:])  # decoder output layer + log_c: a third of the arena, final first
+            hip.check(lib.cradle_stream_wait_event(cs, ev[0].end), "stream_wait_event")
+            parallel._all_reduce(a.grad[o_dec:o_out])
+            hip.check(lib.cradle_stream_wait_event(cs, ev[1].begin), "stream_wait_event")
             parallel._all_reduce(a.grad[o_enc:o_dec])
             self.comm_stream.wait_stream(cur)  # q(M), q(E|M), q(qc_E): final when the step is
             parallel._all_reduce(a.grad[:o_enc])

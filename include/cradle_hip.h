@@ -183,10 +183,12 @@ typedef struct cradle_step_desc {
   void* ev_k1_end;
   void* ev_gemm_begin;    /* optional hipEvent_t recorded before / after the largest GEMM of the step (decoder */
   void* ev_gemm_end;      /* output layer forward, 2*P*N*G*Hd flop); NULL = off; ignored by the graphed entry */
-  void* ev_bucket[2];     /* optional hipEvent_t fired as soon as a gradient bucket is final (replaces DDP's
+  void* ev_bucket[3];     /* optional hipEvent_t fired as soon as a gradient bucket is final (replaces DDP's
                              bucketed backward hooks under Lightning's ddp strategy, train_norman.py:89-97):
-                             [0] decoder gradients (d_dec.*, d_log_concentration), [1] basal-encoder gradients
-                             (d_enc.*); the rest is final with the step.  NULL = off; ignored when graphed */
+                             [0] the decoder's output layer (d_dec.W_head, d_dec.b_head, d_log_concentration:
+                             a third of all parameters, final first), [1] the other decoder gradients,
+                             [2] basal-encoder gradients (d_enc.*); the rest is final with the step.
+                             NULL = off; ignored when graphed */
 } cradle_step_desc;
 
 int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only the sizes are read */
