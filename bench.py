@@ -74,6 +74,22 @@ def k1_pmc_traffic(G, N, P):
     return d.get("traffic_bytes")
 
 
+def measured_copy_gbs(device, mbytes=512, reps=10):
+    """Achievable HBM bandwidth on this device as a plain device-to-device copy sees it (read + write
+    bytes over time): context for the K1 fraction, which is quoted against the 8 TB/s peak."""
+    n = mbytes * (1 << 20) // 4
+    a, b = torch.empty(n, device=device), torch.empty(n, device=device)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def gemm_flops_fwd(s, kmax=None):
     """Forward MLP GEMM flops of one step in the minimal form of SURVEY 8(d) (2 flops per MAC); the
     embedding encoder is counted for the treatment slots the step evaluates."""
@@ -251,6 +267,7 @@ def main():
                 "kernel": "nb_rows_kernel<BWD> (K1 fused fwd+bwd, one decoder variant per launch)",
                 "launch_us": t_k1 * 1e6, "launches_per_step": float(V), "launches_timed": len(k1),
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "copy_gbs_measured": measured_copy_gbs(device),
             }
         # MFMA side: minimal-form GEMM flops of the step (fwd+bwd = 3x fwd) over the whole
         # step time, against the dense fp32 matrix-core peak -- a lower bound on MFMA utilisation
