@@ -312,6 +312,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(shape)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0 is still reading its events / printing: leave together
         dist.destroy_process_group()
 
 
