@@ -467,6 +467,24 @@ int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* d) {
   return carve(*d, nullptr, w);
 }
 
+// Where an intermediate of the last step lives inside desc->workspace (for parity tests: the mask and
+// the latent draws are compared with the reference's own).  name: "mask" (2P*Tc*L, rows (particle,
+// slot)), "E" (same), "qc_E" (2P*Q*L), "z_offset" (P*N rows of [z_basal | D@(E*mask)], ld 2L),
+// "logits" (P*N*G; overwritten by d logits when gradients were computed).  Returns the element
+// count and the pointer, or -1 for an unknown name.
+int64_t cradle_elbo_step_intermediate(const cradle_step_desc* d, const char* name, const float** ptr) {
+  if (!d || !name || !ptr || !d->workspace) return -1;
+  Work w;
+  carve(*d, d->workspace, w);
+  const int64_t PP = 2ll * d->P, PN = (int64_t)d->P * d->N, Tc = w.plan.Tc;
+  if (!strcmp(name, "mask")) { *ptr = w.mask; return PP * Tc * d->L; }
+  if (!strcmp(name, "E")) { *ptr = w.E; return PP * Tc * d->L; }
+  if (!strcmp(name, "qc_E")) { *ptr = w.qcE; return PP * d->Q * d->L; }
+  if (!strcmp(name, "z_offset")) { *ptr = w.zoff; return PN * 2 * d->L; }
+  if (!strcmp(name, "logits")) { *ptr = w.logits; return PN * d->G; }
+  return -1;
+}
+
 }  // extern "C"
 
 namespace {

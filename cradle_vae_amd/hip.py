@@ -48,6 +48,7 @@ PROTOTYPES = {
     "cradle_gemm_f32_repeat": (i32, [ctypes.c_void_p, c_float_p, i64, i32, c_stream]),
     "cradle_elbo_step_workspace_bytes": (i64, [ctypes.c_void_p]),
     "cradle_elbo_step": (i32, [ctypes.c_void_p, c_stream]),
+    "cradle_elbo_step_intermediate": (i64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
     "cradle_elbo_step_graphed": (i32, [ctypes.c_void_p, c_stream, ctypes.POINTER(ctypes.c_int)]),
     "cradle_adam_step": (
         i32,

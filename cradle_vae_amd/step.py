@@ -306,6 +306,17 @@ class FusedElboStep:
             self.check_flags()
         return self.out
 
+    def intermediate(self, name: str) -> torch.Tensor:
+        """Copy of an intermediate of the last step ("mask", "E", "qc_E", "z_offset", "logits"), read out of
+        the workspace through cradle_elbo_step_intermediate -- for parity tests."""
+        p = ctypes.c_void_p()
+        n = self.lib.cradle_elbo_step_intermediate(ctypes.byref(self.desc), name.encode(), ctypes.byref(p))
+        if n < 0:
+            raise hip.CradleHipError(f"unknown intermediate {name!r}")
+        off = (p.value - self.workspace.data_ptr()) // 4
+        torch.cuda.synchronize()
+        return self.workspace[off:off + n].clone()
+
     def check_flags(self):
         f = int(self.flags.item())
         if f & 1:

@@ -192,6 +192,11 @@ typedef struct cradle_step_desc {
 } cradle_step_desc;
 
 int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only the sizes are read */
+/* Inspection (parity tests): where an intermediate of the last step lives inside desc->workspace.
+ * name: "mask", "E" (2P*Tc*L each, rows (particle, treatment slot): the guide's draws of
+ * correlated_normal_guide.py:132-160), "qc_E" (2P*Q*L), "z_offset" (P*N rows [z_basal | D@(E*mask)], ld 2L:
+ * the decoder input of model.py:121), "logits" (P*N*G).  Returns the element count, or -1. */
+int64_t cradle_elbo_step_intermediate(const cradle_step_desc* desc, const char* name, const float** ptr);
 int cradle_elbo_step(const cradle_step_desc* desc, cradle_stream_t stream);
 /* Same result, replayed from a HIP graph: the ~110 launches of the step are captured once per
  * distinct descriptor (every pointer, size and scalar is baked into the graph; up to 48 descriptors

@@ -91,6 +91,12 @@ def elbo_case(name, shape, seed, mutate=None, **cfg_over):
             out[f"{tag}/metrics/{k}"] = v.numpy()
         for k, v in grads.items():
             out[f"{tag}/grads/{k}"] = v.numpy()
+        ref_samples = rh.reference_guide_samples(lm, cast(batch), cast(noise), cfg["n_particles"])
+        for k, v in ref_samples.items():
+            out[f"{tag}/samples/{k}"] = v.numpy()
+        _, o_samples = co.guide_forward(cast(params), cast(noise), cfg["n_particles"], X=cast(batch)["X"],
+                                        D=cast(batch)["D"], qc=cast(batch)["qc"])
+        assert torch.equal(o_samples["mask"].detach(), ref_samples["mask"]), (name, tag, "mask")
         # the oracle must reproduce the reference before a fixture is written
         ol, om, _, og = co.elbo_loss_and_grads(
             cast(params), X=cast(batch)["X"], D=cast(batch)["D"], qc=cast(batch)["qc"], cfX=cast(batch)["cfX"],

@@ -286,6 +286,16 @@ def build_reference_loss_module(ref, params: Dict[str, torch.Tensor], cfg: Dict,
     return loss_module
 
 
+def reference_guide_samples(loss_module, batch, noise, n_particles):
+    """The reference guide's own draws for the main pass (correlated_normal_guide.py:102-209) with
+    the noise injected: mask (hard 0/1), E, qc_E, z_basal -- what "exact mask gathers" is pinned to."""
+    q = guide_noise_queue(noise)
+    with torch.no_grad(), default_dtype(batch["X"].dtype), injected_noise(q) as rest:
+        _, samples = loss_module.guide(X=batch["X"], D=batch["D"], qc=batch["qc"], n_particles=n_particles)
+        assert not rest, "reference consumed less noise than queued"
+    return {k: samples[k].detach().clone() for k in ("mask", "E", "qc_E", "z_basal")}
+
+
 def reference_loss_and_grads(loss_module, batch, noise, cf_noise, n_particles):
     """loss_module.loss(...) + backward, with both guide passes' noise injected."""
     for p in loss_module.parameters():

@@ -34,6 +34,7 @@ def load_elbo(name, dtype=torch.float32, device="cpu"):
             loss=float(z[f"{tag}/loss"]),
             metrics={k: float(v) for k, v in _group(z, f"{tag}/metrics").items()},
             grads=_group(z, f"{tag}/grads"),
+            samples=_group(z, f"{tag}/samples"),  # the reference guide's own draws: mask, E, qc_E, z_basal
         )
     return case
 

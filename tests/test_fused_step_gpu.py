@@ -171,3 +171,23 @@ def test_graph_replay_equals_eager_launch():
     assert torch.allclose(out_st, out2_e, rtol=1e-6, atol=1e-6) and torch.allclose(out_st1, out_e, rtol=1e-6, atol=1e-6)
     assert float((g_st - g2_e).abs().max()) <= 1e-6 * float(g2_e.abs().max())
     assert isinstance(hip.load().cradle_last_error(), bytes)
+
+
+@pytest.mark.parametrize("name", gio.elbo_cases())
+def test_fused_step_draws_match_reference(name):
+    """The hot path's own intermediates against the reference guide's draws (same injected noise):
+    the straight-through mask bit-exact, E / qc_E / z_basal within fp32 GEMM tolerance."""
+    case = gio.load_elbo(name, torch.float32, DEV)
+    lm = build_loss_module(case)
+    run_fused(lm, case)
+    fs, cfg = lm._fused, case["cfg"]
+    P, N, T, L, Q = cfg["n_particles"], case["batch"]["X"].shape[0], cfg["n_treatments"], cfg["n_latent"], cfg["n_qc"]
+    ref = case["f64"]["samples"]
+    mask = fs.intermediate("mask").view(2 * P, T, L)[:P].cpu().double()  # rows P.. are the counterfactual pass
+    assert torch.equal(mask, ref["mask"].double())
+    got = dict(E=fs.intermediate("E").view(2 * P, T, L)[:P], qc_E=fs.intermediate("qc_E").view(2 * P, Q, L)[:P],
+               z_basal=fs.intermediate("z_offset").view(P, N, 2 * L)[:, :, :L])
+    for k, v in got.items():
+        r = ref[k].double()
+        err = float((v.cpu().double() - r).abs().max()) / max(float(r.abs().max()), 1e-6)
+        assert err <= 2e-5, (k, err)

@@ -60,3 +60,20 @@ def test_modular_loss_matches_reference(name):
     loss.backward()
     grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in lm.named_parameters()}
     check_against_golden(case, loss, metrics, grads)
+
+
+@pytest.mark.parametrize("name", gio.elbo_cases())
+def test_guide_samples_match_reference(name):
+    """guide.forward on the GPU against the reference guide's own draws (same injected noise): the
+    mask bit-exact, the reparameterised Normal samples within fp32 GEMM tolerance."""
+    case = gio.load_elbo(name, torch.float32, DEV)
+    lm = build_loss_module(case)
+    b, cfg = case["batch"], case["cfg"]
+    with torch.no_grad():
+        _, s = lm.guide(X=b["X"], D=b["D"], qc=b["qc"], n_particles=cfg["n_particles"], noise=case["noise"])
+    ref = case["f64"]["samples"]
+    assert torch.equal(s["mask"].cpu().double(), ref["mask"].double())
+    for k in ("E", "qc_E", "z_basal"):
+        r = ref[k].double()
+        err = float((s[k].cpu().double() - r).abs().max()) / max(float(r.abs().max()), 1e-6)
+        assert err <= 2e-5, (k, err)

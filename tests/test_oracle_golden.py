@@ -83,3 +83,20 @@ def test_predictor_fixture():
         got = co.ate_from_draws(Xc, Xa, method)
         ref = ate[method]
         assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max())), method
+
+
+@pytest.mark.parametrize("name", gio.elbo_cases())
+@pytest.mark.parametrize("tag,dtype,rtol", [("f64", torch.float64, 1e-12), ("f32", torch.float32, 2e-6)])
+def test_guide_samples_match_reference(name, tag, dtype, rtol):
+    """The straight-through mask is a hard 0/1 tensor: bit-exact against the reference's own draw;
+    E, qc_E, z_basal are reparameterised Normal samples (floating point)."""
+    case = gio.load_elbo(name, dtype)
+    b, cfg = case["batch"], case["cfg"]
+    _, s = co.guide_forward(case["params"], case["noise"], cfg["n_particles"], X=b["X"], D=b["D"], qc=b["qc"])
+    ref = case[tag]["samples"]
+    assert set(ref) == {"mask", "E", "qc_E", "z_basal"}
+    assert torch.equal(s["mask"].detach().to(ref["mask"].dtype), ref["mask"])
+    for k in ("E", "qc_E", "z_basal"):
+        r = ref[k]
+        err = float((s[k].detach().to(r.dtype) - r).abs().max()) / max(float(r.abs().max()), 1e-6)
+        assert err <= 50 * rtol, (k, err)
