@@ -119,3 +119,55 @@ def test_rccl_backend_bucketed_allreduce_single_rank():
         a, b = out[1], out[0]
     assert torch.equal(a[0], b[0]) and a[1] == b[1], "bucketed and single RCCL all-reduce disagree"
     assert all(x == x for x in a[1])
+
+
+def _ate_kwargs(case):
+    ate = case["ate"]
+    Q = case["cfg"]["n_qc"]
+    return dict(dosages_alt=ate["D_alt"], dosages_control=ate["D_control"], quality=torch.ones(1, Q),
+                method="perturbseq", n_particles=24, condition_values=dict(library_size=1e4 * torch.ones(1)),
+                batch_size=4, seed=5)
+
+
+def _ate_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from tests import golden_io as gio
+        from tests.test_predictor_gpu import _predictor
+
+        torch.cuda.set_device(0)
+        case = gio.load_predictor("tiny", torch.float32, "cuda:0")
+        res = _predictor(case).estimate_average_treatment_effects(**_ate_kwargs(case))
+        out[rank] = torch.from_numpy(res.X).clone()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_particle_parallel_ate_equals_single_process():
+    """ATE with its particle chunks sharded over two ranks (real NB sampler, counter-based draws keyed by
+    chunk, one sum all-reduce) against the same call in one process: equal up to the fp32 order of the sum."""
+    from tests import golden_io as gio
+    from tests.test_predictor_gpu import _predictor
+
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_ate_worker, args=(r, port, out)) for r in range(WORLD)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=150)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        assert sorted(out.keys()) == [0, 1], "a rank failed"
+        a, b = out[0], out[1]
+    assert torch.equal(a, b), "ranks disagree after the all-reduce"
+    case = gio.load_predictor("tiny", torch.float32, "cuda:0")
+    single = torch.from_numpy(_predictor(case).estimate_average_treatment_effects(**_ate_kwargs(case)).X)
+    assert torch.isfinite(single).all() and float(single.abs().max()) > 0
+    assert torch.allclose(a, single, rtol=1e-5, atol=1e-5 * float(single.abs().max()))
