@@ -154,6 +154,30 @@ def cpu_baseline(shape, seconds_budget=25.0):
     }
 
 
+def secondary_shape(name, device, args):
+    """The same step at the Replogle-like shape (north_star quotes both), measured after the main
+    region on the same device: side information, not the headline metric."""
+    from cradle_vae_amd import synthetic as syn
+    from cradle_vae_amd.trainer import TrainStep
+
+    shape = syn.SHAPES[name]
+    lm, batch = build(shape, device, seed=1000)
+    st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=1)
+    steps = max(10, min(args.steps, 50))
+    for _ in range(5):
+        st(batch, n_particles=shape.n_particles)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st(batch, n_particles=shape.n_particles)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": shape.n_cells / dt, "unit": "cells/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "workload": f"{shape.name}: N={shape.n_cells}, P={shape.n_particles}, G={shape.n_phenos}, "
+                        f"T={shape.n_treatments} ({min(shape.n_treatments, shape.n_cells * lm.max_dosages_per_cell)} "
+                        f"treatment slots), L={shape.n_latent}"}
+
+
 def trace(msg):
     if os.environ.get("CRADLE_BENCH_TRACE"):
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
@@ -167,6 +191,7 @@ def main():
     ap.add_argument("--shape", default="norman")
     ap.add_argument("--step-impl", default="auto", choices=["auto", "fused", "modular"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Replogle-shaped side measurement (N=1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph instead of launching its kernels on three streams")
     args = ap.parse_args()
@@ -308,6 +333,8 @@ def main():
             "roofline": roofline,
             "mfma": mfma,
         }
+        if world == 1 and args.shape == "norman" and not args.no_secondary:
+            out["replogle_shape"] = secondary_shape("replogle", device, args)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(shape)
         print(json.dumps(out), flush=True)
