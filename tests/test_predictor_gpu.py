@@ -220,3 +220,28 @@ def test_sample_observations_and_sampled_ate_statistics():
     assert good.X.shape == (3 * n, case["cfg"]["n_phenos"]) == bad.X.shape
     assert (good.X >= 0).all() and np.array_equal(good.X, np.round(good.X))
     assert list(good.obs["perturbation_idx"][:4]) == [0, 0, 0, 1]
+
+
+def test_sampler_draws_do_not_depend_on_the_particle_split():
+    """Philox counters are (gene, row, draw): the same seed gives the same draws whether one workgroup
+    walks all particles of a condition (no workspace) or they are split over many (workspace)."""
+    from cradle_vae_amd import hip, ops
+
+    P, C, G = 96, 5, 128
+    logits, log_c, lib = _sampler_inputs(P, C, G, seed=11)
+    consts = ops.nb_gene_consts(log_c)
+    lib_ = hip.load()
+    outs = []
+    for use_ws in (False, True):
+        sums = torch.zeros((C, G), device=DEV)
+        samples = torch.empty((P * C, G), device=DEV)
+        need = lib_.cradle_nb_sample_workspace_floats(P, C, G)
+        assert need > 0
+        ws = torch.empty(need, device=DEV) if use_ws else None
+        hip.check(lib_.cradle_nb_sample_accumulate_ws(
+            hip.ptr(logits), logits.stride(0), hip.ptr(lib), lib.numel(), hip.ptr(consts), hip.ptr(sums), hip.ptr(samples),
+            P, C, G, 1, 0, 77, 0, hip.ptr(ws), need if use_ws else 0, hip.stream()), "nb_sample_accumulate_ws")
+        torch.cuda.synchronize()
+        outs.append((sums.clone(), samples.clone()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-4)
