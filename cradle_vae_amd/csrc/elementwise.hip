@@ -409,11 +409,15 @@ __device__ __forceinline__ GaussVals gauss_vals(float mean_raw, float lv_raw) {
   return g;
 }
 
-// q(E|M): rows = PP*Tc (particle, slot), also writes mask*E for the gathers (model.py:121, guide :186-188).
+// The draw itself, written once so that every kernel that needs E[p,t,l] gets the same bits.
+__device__ __forceinline__ float gauss_draw(const GaussVals& g, float ep) { return fmaf(g.sd, ep, g.mean); }
+
+// q(E|M): rows = PP*Tc (particle, slot).  Off the critical path: the gather that feeds the encoders
+// (gather_offsets_kernel) evaluates the draws it needs itself; this kernel keeps E, sd and the
+// log-ratio sums for the loss and the backward pass.
 __global__ __launch_bounds__(256) void gaussE_fwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
-                                                         const float* __restrict__ mask, const float* __restrict__ ploc,
-                                                         const float* __restrict__ pscale, float* __restrict__ E,
-                                                         float* __restrict__ sd, float* __restrict__ ME, float* __restrict__ S,
+                                                         const float* __restrict__ ploc, const float* __restrict__ pscale,
+                                                         float* __restrict__ E, float* __restrict__ sd, float* __restrict__ S,
                                                          int rows, int T, int Tc, const int* __restrict__ tmap, int L) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -423,7 +427,6 @@ __global__ __launch_bounds__(256) void gaussE_fwd_kernel(const float* __restrict
     for (int l = lane; l < L; l += 64) {
       E[(int64_t)row * L + l] = 0.f;
       sd[(int64_t)row * L + l] = 1.f;
-      ME[(int64_t)row * L + l] = 0.f;
     }
     if (lane == 0) S[row] = 0.f;
     return;
@@ -433,10 +436,9 @@ __global__ __launch_bounds__(256) void gaussE_fwd_kernel(const float* __restrict
   for (int l = lane; l < L; l += 64) {
     const GaussVals g = gauss_vals(heads[(int64_t)row * 2 * L + l], heads[(int64_t)row * 2 * L + L + l]);
     const float ep = erow[l];
-    const float s = g.mean + g.sd * ep;
+    const float s = gauss_draw(g, ep);
     E[(int64_t)row * L + l] = s;
     sd[(int64_t)row * L + l] = g.sd;
-    ME[(int64_t)row * L + l] = s * mask[(int64_t)row * L + l];
     const float pl = ploc[t * L + l], ps = pscale[t * L + l];
     const float d = s - pl;
     acc += -(d * d) / (2.0f * ps * ps) - logf(ps) + 0.5f * ep * ep + logf(g.sd);
@@ -445,11 +447,11 @@ __global__ __launch_bounds__(256) void gaussE_fwd_kernel(const float* __restrict
   if (lane == 0) S[row] = acc;
 }
 
-int gaussE_fwd(const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale, float* E,
-               float* sd, float* ME, float* S, int PP, int T, int Tc, const int* tmap, int L, hipStream_t stream) {
+int gaussE_fwd(const float* heads, const float* eps, const float* ploc, const float* pscale, float* E, float* sd, float* S,
+               int PP, int T, int Tc, const int* tmap, int L, hipStream_t stream) {
   const int rows = PP * Tc;
-  hipLaunchKernelGGL(gaussE_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, heads, eps, mask, ploc, pscale, E, sd,
-                     ME, S, rows, T, Tc, tmap, L);
+  hipLaunchKernelGGL(gaussE_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, heads, eps, ploc, pscale, E, sd, S,
+                     rows, T, Tc, tmap, L);
   CRADLE_CHECK_LAUNCH("gaussE_fwd_kernel");
   return CRADLE_OK;
 }
@@ -461,43 +463,64 @@ __device__ __forceinline__ void gauss_head_grads(const GaussVals& g, float ds, f
   dlv = g.var_ok ? dsd * g.e / (2.0f * g.sd) : 0.f;
 }
 
-__global__ __launch_bounds__(256) void gaussE_bwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
+// Backward of q(E|M) fused with the scatter that produces its incoming gradient: one workgroup per
+// (slot, particle) first sums d(mask*E)[pp,t,:] = sum_{cells n of t} D[n,t] * g[pp,n,:] over the CSC
+// column of its treatment (g = a1 + a2 for the main pass, b1 for the counterfactual pass), then
+// applies the Gaussian head's closed-form backward.  No (2P, Tc, L) gradient buffer in between.
+__global__ __launch_bounds__(256) void gaussE_bwd_kernel(const int* __restrict__ tstart, const int* __restrict__ csc_cell,
+                                                         const float* __restrict__ csc_val, int entries,
+                                                         const float* __restrict__ a1, int64_t ld1, const float* __restrict__ a2,
+                                                         int64_t ld2, const float* __restrict__ b1, int64_t ldb1,
+                                                         const float* __restrict__ heads, const float* __restrict__ eps,
                                                          const float* __restrict__ mask, const float* __restrict__ ploc,
                                                          const float* __restrict__ pscale, const float* __restrict__ E,
-                                                         const float* __restrict__ sd, const float* __restrict__ dME,
-                                                         const float* __restrict__ coefTc, float* __restrict__ dheads,
-                                                         float* __restrict__ dmask, int PP, int P, int T, int Tc,
-                                                         const int* __restrict__ tmap, int L) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)PP * Tc * L) return;
-  const int l = i % L;
-  const int64_t row = i / L;
-  const int j = row % Tc, pp = row / Tc;
+                                                         const float* __restrict__ sd, const float* __restrict__ coefTc,
+                                                         float* __restrict__ dheads, float* __restrict__ dmask, int P, int N,
+                                                         int T, int Tc, const int* __restrict__ tmap, int L) {
+  const int j = blockIdx.x, pp = blockIdx.y;
+  const int64_t row = (int64_t)pp * Tc + j;
   const int t = tmap ? tmap[j] : j;
   if (t < 0) {  // unused slot: nothing flows back
-    dmask[i] = 0.f;
-    dheads[row * 2 * L + l] = 0.f;
-    dheads[row * 2 * L + L + l] = 0.f;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+      dmask[row * L + l] = 0.f;
+      dheads[row * 2 * L + l] = 0.f;
+      dheads[row * 2 * L + L + l] = 0.f;
+    }
     return;
   }
-  const GaussVals g = gauss_vals(heads[row * 2 * L + l], heads[row * 2 * L + L + l]);
-  const float s = E[i], ep = eps[((int64_t)pp * T + t) * L + l], dme = dME[i];
+  const int e0 = tstart[t], e1 = min(tstart[t + 1], entries);  // never past the column arrays
   const float coef = pp < P ? coefTc[j] : 0.f;
-  const float pl = ploc[t * L + l], ps = pscale[t * L + l];
-  const float ds = dme * mask[i] + coef * (-(s - pl) / (ps * ps));
-  dmask[i] = dme * s;
-  float dmean, dlv;
-  gauss_head_grads(g, ds, ep, coef / sd[i], dmean, dlv);
-  dheads[row * 2 * L + l] = dmean;
-  dheads[row * 2 * L + L + l] = dlv;
+  for (int l = threadIdx.x; l < L; l += blockDim.x) {
+    float dme = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int n = csc_cell[e];
+      if ((unsigned)n >= (unsigned)N) continue;  // defensive: an index the plan did not write
+      float g;
+      if (pp < P) g = a1[((int64_t)pp * N + n) * ld1 + l] + a2[((int64_t)pp * N + n) * ld2 + l];
+      else g = b1[((int64_t)(pp - P) * N + n) * ldb1 + l];
+      dme = fmaf(csc_val[e], g, dme);
+    }
+    const int64_t i = row * L + l;
+    const GaussVals g = gauss_vals(heads[row * 2 * L + l], heads[row * 2 * L + L + l]);
+    const float s = E[i], ep = eps[((int64_t)pp * T + t) * L + l];
+    const float pl = ploc[t * L + l], ps = pscale[t * L + l];
+    const float ds = dme * mask[i] + coef * (-(s - pl) / (ps * ps));
+    dmask[i] = dme * s;
+    float dmean, dlv;
+    gauss_head_grads(g, ds, ep, coef / sd[i], dmean, dlv);
+    dheads[row * 2 * L + l] = dmean;
+    dheads[row * 2 * L + L + l] = dlv;
+  }
 }
 
-int gaussE_bwd(const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale,
-               const float* E, const float* sd, const float* dME, const float* coefTc, float* dheads, float* dmask, int PP,
-               int P, int T, int Tc, const int* tmap, int L, hipStream_t stream) {
-  const int64_t n = (int64_t)PP * Tc * L;
-  hipLaunchKernelGGL(gaussE_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, heads, eps, mask, ploc,
-                     pscale, E, sd, dME, coefTc, dheads, dmask, PP, P, T, Tc, tmap, L);
+int gaussE_bwd(const DosagePlan& plan, const float* a1, int64_t ld1, const float* a2, int64_t ld2, const float* b1,
+               int64_t ldb1, const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale,
+               const float* E, const float* sd, const float* coefTc, float* dheads, float* dmask, int PP, int P, int N, int T,
+               int L, hipStream_t stream) {
+  const int nt = L <= 64 ? 64 : (L <= 128 ? 128 : 256);  // one pass over the latent columns
+  hipLaunchKernelGGL(gaussE_bwd_kernel, dim3(plan.Tc, PP), dim3(nt), 0, stream, plan.tstart, plan.csc_cell, plan.csc_val,
+                     N * plan.kmax, a1, ld1, a2, ld2, b1, ldb1, heads, eps, mask, ploc, pscale, E, sd, coefTc, dheads, dmask,
+                     P, N, T, plan.Tc, plan.tmap, L);
   CRADLE_CHECK_LAUNCH("gaussE_bwd_kernel");
   return CRADLE_OK;
 }
@@ -682,71 +705,40 @@ int zhead_bwd(const float* heads, const float* eps, const float* z, int64_t ldz,
 // Particles pp < P (main pass) go to offA (a column block of the decoder input [z | off]),
 // pp >= P (counterfactual pass) to offB.
 // =====================================================================================
-__global__ __launch_bounds__(64) void gather_offsets_kernel(const float* __restrict__ ME, const int* __restrict__ ell_idx,
+__global__ __launch_bounds__(64) void gather_offsets_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
+                                                            const float* __restrict__ mask, const int* __restrict__ ell_idx,
                                                             const float* __restrict__ ell_val, int kmax, float* __restrict__ offA,
                                                             int64_t ldA, float* __restrict__ offB, int64_t ldB, int P, int N,
-                                                            int Tc, const int* __restrict__ tpos, int L) {
+                                                            int T, int Tc, const int* __restrict__ tpos, int L) {
   // offB: (2P*N, L) offsets of both guide passes (main rows first), one operand for the encoder GEMMs;
-  // offA: the main pass once more, inside the decoder input [z | offset]
+  // offA: the main pass once more, inside the decoder input [z | offset].
+  // E[pp,t,l]*mask[pp,t,l] is evaluated here from the Gaussian heads for the <= kmax treatments of the
+  // cell (same expression as gaussE_fwd_kernel: same bits), so the encoders do not wait for that kernel.
   const int n = blockIdx.x, pp = blockIdx.y;
   float* out = offB + ((int64_t)pp * N + n) * ldB;
   float* out2 = pp < P ? offA + ((int64_t)pp * N + n) * ldA : nullptr;
-  const float* tab = ME + (int64_t)pp * Tc * L;
   for (int l = threadIdx.x; l < L; l += 64) {
     float acc = 0.f;
     for (int k = 0; k < kmax; ++k) {
       const int t = ell_idx[n * kmax + k];
       if (t < 0) break;
       const int slot = tpos ? tpos[t] : t;
-      if (slot >= 0) acc = fmaf(ell_val[n * kmax + k], tab[(int64_t)slot * L + l], acc);
+      if (slot < 0) continue;
+      const int64_t row = (int64_t)pp * Tc + slot;
+      const GaussVals g = gauss_vals(heads[row * 2 * L + l], heads[row * 2 * L + L + l]);
+      const float s = gauss_draw(g, eps[((int64_t)pp * T + t) * L + l]);
+      acc = fmaf(ell_val[n * kmax + k], s * mask[row * L + l], acc);
     }
     out[l] = acc;
     if (out2) out2[l] = acc;
   }
 }
 
-int gather_offsets(const float* ME, const DosagePlan& plan, float* offA, int64_t ldA, float* offB, int64_t ldB, int PP,
-                   int P, int N, int T, int L, hipStream_t stream) {
-  (void)T;
-  hipLaunchKernelGGL(gather_offsets_kernel, dim3(N, PP), dim3(64), 0, stream, ME, plan.ell_idx, plan.ell_val, plan.kmax,
-                     offA, ldA, offB, ldB, P, N, plan.Tc, plan.tpos, L);
+int gather_offsets(const float* heads, const float* eps, const float* mask, const DosagePlan& plan, float* offA, int64_t ldA,
+                   float* offB, int64_t ldB, int PP, int P, int N, int T, int L, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_offsets_kernel, dim3(N, PP), dim3(64), 0, stream, heads, eps, mask, plan.ell_idx, plan.ell_val,
+                     plan.kmax, offA, ldA, offB, ldB, P, N, T, plan.Tc, plan.tpos, L);
   CRADLE_CHECK_LAUNCH("gather_offsets_kernel");
-  return CRADLE_OK;
-}
-
-// dME[pp,t,:] = sum_{cells n of t} D[n,t] * (a1 + a2)[pp,n,:]   (pp < P)   or  b1[pp-P,n,:]  (pp >= P)
-__global__ __launch_bounds__(256) void scatter_offsets_kernel(const int* __restrict__ tstart, const int* __restrict__ csc_cell,
-                                                             const float* __restrict__ csc_val, const float* __restrict__ a1,
-                                                             int64_t ld1, const float* __restrict__ a2, int64_t ld2,
-                                                             const float* __restrict__ b1, int64_t ldb1, float* __restrict__ dME,
-                                                             int P, int N, int Tc, const int* __restrict__ tmap, int L,
-                                                             int entries) {
-  const int j = blockIdx.x, pp = blockIdx.y;
-  const int t = tmap ? tmap[j] : j;
-  const int e0 = t >= 0 ? tstart[t] : 0;                        // unused slot: zeros
-  const int e1 = t >= 0 ? min(tstart[t + 1], entries) : 0;      // never past the column arrays
-  float* out = dME + ((int64_t)pp * Tc + j) * L;
-  for (int l = threadIdx.x; l < L; l += blockDim.x) {
-    float acc = 0.f;
-    for (int e = e0; e < e1; ++e) {
-      const int n = csc_cell[e];
-      if ((unsigned)n >= (unsigned)N) continue;  // defensive: an index the plan did not write
-      float g;
-      if (pp < P) g = a1[((int64_t)pp * N + n) * ld1 + l] + a2[((int64_t)pp * N + n) * ld2 + l];
-      else g = b1[((int64_t)(pp - P) * N + n) * ldb1 + l];
-      acc = fmaf(csc_val[e], g, acc);
-    }
-    out[l] = acc;
-  }
-}
-
-int scatter_offsets(const DosagePlan& plan, const float* a1, int64_t ld1, const float* a2, int64_t ld2, const float* b1,
-                    int64_t ldb1, float* dME, int PP, int P, int N, int T, int L, hipStream_t stream) {
-  const int nt = L <= 64 ? 64 : (L <= 128 ? 128 : 256);  // one pass over the latent columns
-  (void)T;
-  hipLaunchKernelGGL(scatter_offsets_kernel, dim3(plan.Tc, PP), dim3(nt), 0, stream, plan.tstart, plan.csc_cell, plan.csc_val,
-                     a1, ld1, a2, ld2, b1, ldb1, dME, P, N, plan.Tc, plan.tmap, L, N * plan.kmax);
-  CRADLE_CHECK_LAUNCH("scatter_offsets_kernel");
   return CRADLE_OK;
 }
 

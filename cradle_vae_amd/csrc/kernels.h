@@ -106,12 +106,14 @@ int mask_fwd(const float* logits, const float* u, const float* p_mask_probs, flo
 int mask_bwd(const float* logits, const float* p_mask_probs, float tau, const float* mask, const float* soft,
              const float* dmask_a, const float* dmask_b, const float* coefT, float* dlogits, int PP, int P, int T,
              int Tc, const int* tpos, int L, hipStream_t stream);
-int gaussE_fwd(const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale,
-               float* E, float* sd, float* ME, float* S, int PP, int T, int Tc, const int* tmap, int L,
-               hipStream_t stream);
-int gaussE_bwd(const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale,
-               const float* E, const float* sd, const float* dME, const float* coefTc, float* dheads, float* dmask,
-               int PP, int P, int T, int Tc, const int* tmap, int L, hipStream_t stream);
+int gaussE_fwd(const float* heads, const float* eps, const float* ploc, const float* pscale, float* E, float* sd, float* S,
+               int PP, int T, int Tc, const int* tmap, int L, hipStream_t stream);
+// backward of q(E|M) fused with the scatter of its incoming gradient over the cells of each treatment:
+// d(mask*E)[pp,t,:] = sum_n D[n,t] * (a1 + a2)[pp,n,:] (pp < P) or b1[pp-P,n,:] (pp >= P)
+int gaussE_bwd(const DosagePlan& plan, const float* a1, int64_t ld1, const float* a2, int64_t ld2, const float* b1,
+               int64_t ldb1, const float* heads, const float* eps, const float* mask, const float* ploc, const float* pscale,
+               const float* E, const float* sd, const float* coefTc, float* dheads, float* dmask, int PP, int P, int N, int T,
+               int L, hipStream_t stream);
 int qce_fwd(const float* heads, const float* eps, const float* ploc, const float* pscale, float* qcE, float* sd,
             float* S, float* qsum, int PP, int P, int Q, int L, hipStream_t stream);
 int qce_bwd(const float* heads, const float* eps, const float* ploc, const float* pscale, const float* qcE,
@@ -123,10 +125,8 @@ int zhead_bwd(const float* heads, const float* eps, const float* z, int64_t ldz,
               int64_t lddz, float* dheads, int P, int N, int L, hipStream_t stream);
 
 // ---- elementwise.hip : gathers
-int gather_offsets(const float* ME, const DosagePlan& plan, float* offA, int64_t ldA, float* offB, int64_t ldB, int PP,
-                   int P, int N, int T, int L, hipStream_t stream);
-int scatter_offsets(const DosagePlan& plan, const float* a1, int64_t ld1, const float* a2, int64_t ld2, const float* b1,
-                    int64_t ldb1, float* dME, int PP, int P, int N, int T, int L, hipStream_t stream);
+int gather_offsets(const float* heads, const float* eps, const float* mask, const DosagePlan& plan, float* offA, int64_t ldA,
+                   float* offB, int64_t ldB, int PP, int P, int N, int T, int L, hipStream_t stream);
 int enc_combine_fwd(const float* xW, const float* offW, const float* vq, const float* bias, const float* qc, float* h,
                     int P, int N, int Q, int H, hipStream_t stream);
 // dvq (the qc-embedding part) is produced on `vq_stream`: its consumers are off the critical path

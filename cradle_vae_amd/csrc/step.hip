@@ -115,7 +115,7 @@ struct Work {
   CellPrep cp;
   float *hascf, *gene_consts;
   float *mask, *soft, *Smask, *W0tT;
-  float *yE[CRADLE_MAX_LAYERS], *rE[CRADLE_MAX_LAYERS], *headsE, *sdE, *E, *ME, *SE;
+  float *yE[CRADLE_MAX_LAYERS], *rE[CRADLE_MAX_LAYERS], *headsE, *sdE, *E, *SE;
   float *yq[CRADLE_MAX_LAYERS], *rq[CRADLE_MAX_LAYERS], *headsq, *sdq, *qcE, *Sq, *qsum, *ones_q;
   float *xn, *xW, *offB, *zoff, *offW, *vq;
   float *yz[CRADLE_MAX_LAYERS], *rz[CRADLE_MAX_LAYERS], *headsz, *sdz, *ltz, *klrow;
@@ -125,7 +125,7 @@ struct Work {
   // layer because the weight-gradient GEMMs read them from a side stream
   float *Gd[2], *dad[CRADLE_MAX_LAYERS], *dzoff, *dwq, *dq_dec;
   float *dheadsz, *Gz[2], *daz[CRADLE_MAX_LAYERS], *doffW, *dxW, *dvq, *doffenc, *dq_enc;
-  float *dME, *dmaskME, *dheadsE, *GE[2], *daE[CRADLE_MAX_LAYERS], *dmask_enc;
+  float *dmaskME, *dheadsE, *GE[2], *daE[CRADLE_MAX_LAYERS], *dmask_enc;
   float *dheadsq, *Gq[2], *daq[CRADLE_MAX_LAYERS];
   float* splitk[3];  // one split-K scratch per stream
   int64_t nbws_floats;
@@ -178,7 +178,6 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   w.headsE = a.take<float>(PT * 2 * L);
   w.sdE = a.take<float>(PT * L);
   w.E = a.take<float>(PT * L);
-  w.ME = a.take<float>(PT * L);
   w.SE = a.take<float>(PT);
   for (int k = 0; k < d.qce.n_layers; ++k) {
     w.yq[k] = a.take<float>((int64_t)Q * Hm);
@@ -232,7 +231,6 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   w.dvq = a.take<float>((int64_t)PP * Q * He);
   w.doffenc = a.take<float>(2 * PN * L);
   w.dq_enc = a.take<float>((int64_t)PP * Q * L);
-  w.dME = a.take<float>(PT * L);
   w.dmaskME = a.take<float>(PT * L);
   w.dheadsE = a.take<float>(PT * 2 * L);
   w.dmask_enc = a.take<float>(PT * L);
@@ -562,10 +560,12 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   trunk_fwd(c, d.emb, PT, Hm, w.yE, w.rE);
   head_fwd(c, d.emb, PT, Hm, 2 * L, w.yE[d.emb.n_layers - 1], w.headsE);
   if (c.rc) return c.rc;
-  STEP(gaussE_fwd(w.headsE, d.eps_E, w.mask, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.ME, w.SE, PP, T, Tc, w.plan.tmap, L,
-                  s));
+  // E, its scale and the log-ratio sums are needed by the loss and the backward pass only: stream 2 (idle by
+  // now); the gather below draws the E it needs from the heads itself
+  c.after(2, 0);
+  STEP(gaussE_fwd(w.headsE, d.eps_E, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.SE, PP, T, Tc, w.plan.tmap, L, s2));
   if (!w.plan.tmap) c.wait(0, ev_plan);
-  STEP(gather_offsets(w.ME, w.plan, w.zoff + L, 2 * L, w.offB, L, PP, P, N, T, L, s));     // D @ (mask*E)
+  STEP(gather_offsets(w.headsE, d.eps_E, w.mask, w.plan, w.zoff + L, 2 * L, w.offB, L, PP, P, N, T, L, s));  // D @ (mask*E)
   c.gemm(GEMM_NT, gp(w.offB, L, Wenc0 + G, ldenc, w.offW, He, 2 * PN, He, L));  // offsets . Woff^T, both passes
   c.after(0, 1);
   c.after(0, 2);
@@ -667,9 +667,8 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   if (c.rc) return c.rc;
 
   // q(E|M), q(M)
-  STEP(scatter_offsets(w.plan, w.dzoff + L, 2 * L, w.doffenc, L, w.doffenc + (int64_t)PN * L, L, w.dME, PP, P, N, T, L, s));
-  STEP(gaussE_bwd(w.headsE, d.eps_E, w.mask, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.dME, w.cp.coefTc, w.dheadsE, w.dmaskME,
-                  PP, P, T, Tc, w.plan.tmap, L, s));
+  STEP(gaussE_bwd(w.plan, w.dzoff + L, 2 * L, w.doffenc, L, w.doffenc + (int64_t)PN * L, L, w.headsE, d.eps_E, w.mask,
+                  d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.cp.coefTc, w.dheadsE, w.dmaskME, PP, P, N, T, L, s));
   const float* da0E = head_trunk_bwd(c, d.emb, d.d_emb, PT, Hm, 2 * L, w.dheadsE, w.yE, w.rE, w.GE, w.daE, 0, 1, 1);
   if (c.rc) return c.rc;
   c.after(1, 0);
