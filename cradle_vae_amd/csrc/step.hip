@@ -4,7 +4,7 @@
 // in parameter / gradient / batch / noise pointers and one workspace, and gets the loss terms
 // and every parameter gradient back.  Capturable into a HIP graph.
 //
-// Algebraic restructurings relative to the reference (i-vii; all exact up to
+// Algebraic restructurings relative to the reference (i-vii, and viii of DESIGN.md; all exact up to
 // fp32 reassociation):
 //   (i)   x_good / x_bad are not sampled (model.py:131-132 draws are unused by the loss);
 //   (ii)  logstd(X) Wx^T and logstd(cfX) Wx^T are computed once, not once per particle and call;
@@ -13,7 +13,9 @@
 //   (iv)  qc in {0,1}: only the live decoder variant of each cell is decoded and scored;
 //   (v)   the lgamma terms of the likelihood are evaluated per (cell, gene), not per particle;
 //   (vi)  the one-hot block of the embedding encoder's first layer is a table lookup;
-//   (vii) every matmul(D, .) / matmul(qc, .) is a gather / scatter over <= kmax non-zeros per cell.
+//   (vii) every matmul(D, .) / matmul(qc, .) is a gather / scatter over <= kmax non-zeros per cell;
+//   (viii) when N*kmax < T, q(M) and q(E|M) are evaluated for the treatments present in the batch only
+//          (compact treatment axis, kernels.h DosagePlan): the others have plate weight zero.
 #include <stdlib.h>
 #include <string.h>
 
