@@ -15,8 +15,9 @@ uses live in ``pyro-ppl==1.9.1`` (reference ``environment.yml:177``), which is n
 installed anywhere in this pipeline: ``pyro.distributions.GammaPoisson`` and
 ``pyro.distributions.RelaxedBernoulliStraightThrough``.  Their published algorithms
 are restated here (``gamma_poisson_log_prob``, ``relaxed_bernoulli_st_rsample``);
-for those two pieces parity is pinned by closed-form cross-checks
-(``scipy.stats.nbinom``) only.
+for those two pieces: PARITY UNPINNED by the reference (it ships neither the classes nor
+vectors for them) -- they are held by closed-form cross-checks (``scipy.stats.nbinom``,
+``torch.distributions.NegativeBinomial``) only.
 
 All citations ``file:line`` are relative to ``/root/reference``.
 """
