@@ -10,7 +10,7 @@ cradle_vae/loss_module.py:12-24).
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, Optional
+from typing import Iterable, Optional
 
 import torch
 

@@ -10,14 +10,13 @@ are CUDA-only third-party tools outside this path; it raises ``NotImplementedErr
 from __future__ import annotations
 
 import math
-from typing import Dict, Iterable, Literal, Optional, Sequence, Union
+from typing import Dict, Iterable, Literal, Optional, Sequence
 
 import numpy as np
 import pandas as pd
 import torch
 from torch import nn
 
-from . import ops
 from .ate import estimate_model_average_treatment_effect
 
 try:  # pragma: no cover - anndata is absent from the build image
