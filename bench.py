@@ -103,9 +103,37 @@ def gemm_flops_fwd(s, kmax=None):
     return float(f_enc + f_dec + f_emb)
 
 
-def cpu_baseline(shape, seconds_budget=25.0):
+def loss_parity(lm, shape, batch, device):
+    """One forward of the fused HIP step on the bench's own batch and its trained parameters against the
+    fp64 CPU oracle on the same injected noise -> relative error of the loss and the largest relative error
+    over the loss terms (the parity bar is 1e-4, tests/test_fused_fullsize_gpu.py)."""
+    from cradle_vae_amd import synthetic as syn
+    from oracle import cradle_oracle as co
+
+    n1, n2 = syn.make_noise(shape, 100), syn.make_noise(shape, 200)
+    dev = lambda d: {k: v.to(device) for k, v in d.items()}
+    with torch.no_grad():
+        loss, metrics = lm.loss(
+            X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"],
+            qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"],
+            condition_values={"library_size": batch["library_size"]}, n_particles=shape.n_particles,
+            noise=dev(n1), cf_noise=dev(n2))
+    torch.cuda.synchronize()
+    f64 = lambda d: {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in d.items()}
+    params, b = f64(lm.state_dict()), f64({k: v for k, v in batch.items() if k != "idx"})
+    with torch.no_grad():
+        ref, ref_metrics, _ = co.elbo_loss(
+            params, X=b["X"], D=b["D"], qc=b["qc"], cfX=b["cfX"], library_size=b["library_size"],
+            D_obs_counts=b["D_obs_counts"], qc_obs_counts=b["qc_obs_counts"], noise=f64(n1), cf_noise=f64(n2),
+            n_particles=shape.n_particles, beta=shape.beta)
+    terms = max(abs(float(metrics[k]) - float(v)) / max(1.0, abs(float(v))) for k, v in ref_metrics.items())
+    return abs(float(loss) - float(ref)) / abs(float(ref)), terms
+
+
+def cpu_baseline(shape, seconds_budget=25.0, as_written=False):
     """The reference's PyTorch path (CPU oracle restatement, fp32, autograd + Adam), timed on
-    this host's cores on a bounded sample of the same workload."""
+    this host's cores on a bounded sample of the same workload.  ``as_written``: with the work the reference
+    does and discards (the x_good/x_bad draws, distribution argument validation)."""
     from cradle_vae_amd import synthetic as syn
     from oracle import cradle_oracle as co
 
@@ -132,7 +160,7 @@ def cpu_baseline(shape, seconds_budget=25.0):
         loss, _, _ = co.elbo_loss(
             p2, X=b["X"], D=b["D"], qc=b["qc"], cfX=b["cfX"], library_size=b["library_size"],
             D_obs_counts=b["D_obs_counts"], qc_obs_counts=b["qc_obs_counts"], noise=n1, cf_noise=n2,
-            n_particles=shape.n_particles, beta=shape.beta)
+            n_particles=shape.n_particles, beta=shape.beta, as_written=as_written)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(leaves, 100.0)
@@ -150,7 +178,9 @@ def cpu_baseline(shape, seconds_budget=25.0):
         "cores": torch.get_num_threads(),
         "kind": "port",
         "sample": f"{len(times)} timed ELBO fwd+bwd+Adam steps of the same {shape.name} batch shape "
-                  f"(oracle/cradle_oracle.py, fp32, minimal form without the unused x draws), median {t:.3f} s/step",
+                  f"(oracle/cradle_oracle.py, fp32, "
+                  + ("as the reference writes it: with the unused x_good/x_bad draws and argument validation"
+                     if as_written else "minimal form without the unused x draws") + f"), median {t:.3f} s/step",
     }
 
 
@@ -193,7 +223,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Replogle-shaped side measurement (N=1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph instead of launching its kernels on three streams")
     args = ap.parse_args()
 
     from cradle_vae_amd import hip, ops
@@ -227,10 +256,7 @@ def main():
     stepper = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=world)
 
     if stepper.fused is not None:
-        stepper.fused.use_graph = args.graph
-        # K1 is timed with HIP events in every step (rank 0): the step then replays as two graphs
-        # with K1 launched between them.  Switched on before the warm-up so that the timed
-        # region holds no graph capture.
+        # K1 and the largest GEMM are timed with HIP events recorded by the C code around their launches (rank 0)
         stepper.fused.k1_events = [] if rank == 0 else None
         stepper.fused.gemm_events = [] if rank == 0 else None
         # every 4th step of the timed region carries the four timing events (each is a barrier packet
@@ -325,7 +351,7 @@ def main():
             "config": {
                 "workload": f"{shape.name}: ELBO fwd+bwd+clip+Adam, N={N} cells/GPU, P={P}, G={G}, "
                             f"T={shape.n_treatments}, L={shape.n_latent}, H={shape.decoder_n_hidden}",
-                "step_impl": stepper.impl, "hip_graph": bool(stepper.fused is not None and stepper.fused.use_graph),
+                "step_impl": stepper.impl,
                 "decoder_variants_per_cell": V, "parallelism": f"dp{world}",
                 "treatment_slots": min(shape.n_treatments, N * lm.max_dosages_per_cell),
                 "loss": float(loss),
@@ -336,7 +362,13 @@ def main():
         if world == 1 and args.shape == "norman" and not args.no_secondary:
             out["replogle_shape"] = secondary_shape("replogle", device, args)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(shape)
+            if stepper.fused is not None:
+                rel, rel_terms = loss_parity(lm, shape, batch, device)
+                out["loss_rel_err_vs_oracle"] = rel
+                out["loss_terms_max_rel_err_vs_oracle"] = rel_terms
+            out["cpu_baseline"] = cpu_baseline(shape, seconds_budget=15.0)
+            aw = cpu_baseline(shape, seconds_budget=12.0, as_written=True)
+            out["cpu_baseline"]["as_written"] = {k: aw[k] for k in ("value", "unit", "sample")}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()  # rank 0 is still reading its events / printing: leave together

@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                                                    float wd, float bc1, float sqrt_bc2, float max_norm, float grad_scale,
-                                                   float* __restrict__ ws) {
+                                                   float* __restrict__ ws, const int* __restrict__ skip_flags) {
+  // the step that produced these gradients rejected its input (cradle_step_desc.flags != 0: a cell with more
+  // than kmax dosages, qc outside {0,1}): its gradients are wrong, so parameters and moments stay as they are
+  if (skip_flags && *skip_flags != 0) return;
   // every workgroup finishes the norm from the kNormBlocks partial sums itself (same order everywhere:
   // same value), which saves a single-workgroup launch between the two passes
   __shared__ float red[4];
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 int adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int step, float max_norm, float grad_scale, float* norm_ws,
-              hipStream_t stream) {
+              const int* skip_flags, hipStream_t stream) {
   CRADLE_CHECK_ARG(params && grads && m && v && norm_ws && n > 0 && step >= 1, "adam_step: bad arguments");
   CRADLE_CHECK_ARG((uintptr_t)grads % 16 == 0, "adam_step: grads must be 16-byte aligned");
   hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, stream, grads, n, norm_ws);
@@ -63,7 +66,7 @@ int adam_step(float* params, const float* grads, float* m, float* v, int64_t n, 
   const float sqrt_bc2 = sqrtf(1.0f - powf(beta2, (float)step));
   const int blocks = (int)min((int64_t)2048, (n + 255) / 256);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, sqrt_bc2, max_norm, grad_scale, norm_ws);
+                     weight_decay, bc1, sqrt_bc2, max_norm, grad_scale, norm_ws, skip_flags);
   CRADLE_CHECK_LAUNCH("adam_step");
   return CRADLE_OK;
 }
@@ -73,12 +76,12 @@ int adam_step(float* params, const float* grads, float* m, float* v, int64_t n, 
 extern "C" {
 
 // norm_ws: cradle_adam_workspace_floats() floats; after the call its last element holds the
-// (scaled, pre-clip) global gradient norm.
+// (scaled, pre-clip) global gradient norm.  skip_flags (device int, may be NULL): non-zero = no update.
 int cradle_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
-                     float grad_scale, float* norm_ws, hipStream_t stream) {
+                     float grad_scale, float* norm_ws, const int* skip_flags, hipStream_t stream) {
   return cradle::adam_step(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, max_norm,
-                           grad_scale, norm_ws, stream);
+                           grad_scale, norm_ws, skip_flags, stream);
 }
 
 int64_t cradle_adam_workspace_floats(void) { return cradle::kNormBlocks + 1; }

@@ -4,10 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
-#define CRADLE_OK 0
-#define CRADLE_ERR_ARG 1
-#define CRADLE_ERR_HIP 2
-#define CRADLE_ERR_UNSUPPORTED 3
+// the public C ABI: status codes, descriptor structs and the prototypes every definition is checked against
+#include "../../include/cradle_hip.h"
 
 // thread-local last-error string, see api.hip
 void cradle_set_error(const char* fmt, ...);

@@ -946,7 +946,7 @@ __global__ __launch_bounds__(1024) void finalize_loss_kernel(const float* __rest
                                                              const float* __restrict__ Smask, const float* __restrict__ SE,
                                                              const float* __restrict__ Sq, const float* __restrict__ cw,
                                                              const float* __restrict__ cwq, float beta, int P, int N, int T,
-                                                             int Q, float* __restrict__ out) {
+                                                             int Q, const int* __restrict__ flags, float* __restrict__ out) {
   __shared__ float red[6][16];
   float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int64_t PN = (int64_t)P * N;
@@ -972,15 +972,18 @@ __global__ __launch_bounds__(1024) void finalize_loss_kernel(const float* __rest
     }
     const float kl = beta * tot[5] / (float)P;
     out[6] = kl;
-    out[0] = loss + kl;
+    // an input the step cannot score (flags != 0) must not pass for a loss: NaN until the caller has dealt with it
+    const bool rejected = *flags != 0;
+    out[0] = rejected ? __int_as_float(0x7fc00000) : loss + kl;
+    if (rejected) out[7] += 1.0f;  // sticky count for the host's occasional look (the flags word is per step)
   }
 }
 
 int finalize_loss(const float* recon, const float* wrec, const float* ltz, const float* klrow, const float* Smask,
                   const float* SE, const float* Sq, const float* cw, const float* cwq, float beta, int P, int N, int T,
-                  int Q, float* out, hipStream_t stream) {
+                  int Q, const int* flags, float* out, hipStream_t stream) {
   hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1024), 0, stream, recon, wrec, ltz, klrow, Smask, SE, Sq, cw, cwq,
-                     beta, P, N, T, Q, out);
+                     beta, P, N, T, Q, flags, out);
   CRADLE_CHECK_LAUNCH("finalize_loss_kernel");
   return CRADLE_OK;
 }

@@ -423,24 +423,6 @@ void cradle_gemm_tune(int tm, int tn, int bk, int depth, int wk, int splitk) {
   if (wk == 4) cradle::g_tune_ws = 1;  // the four-K-group kernels are the single-wave-tile ones
 }
 
-// Public descriptor (include/cradle_hip.h: cradle_gemm_desc).  Field order is ABI.
-struct cradle_gemm_desc {
-  int layout, M, N, K;
-  const float* A; int64_t lda;
-  const float* B; int64_t ldb;
-  float* C; int64_t ldc;
-  float beta;
-  int act;
-  const float* bias;
-  const float* rowbias; int64_t ld_rowbias; int rowbias_mode, rowbias_n;
-  const float* rowscale; int rowscale_n;
-  float* act_out; int64_t ld_act_out;
-  const float* residual; int64_t ld_residual;
-  const float* dact_src; int64_t ld_dact_src;
-  float* C2; int64_t ldc2;
-  float* extra_col;
-};
-
 int cradle_gemm_f32(const cradle_gemm_desc* d, float* workspace, int64_t workspace_floats, hipStream_t stream) {
   CRADLE_CHECK_ARG(d, "gemm: null descriptor");
   GemmParams p = {};

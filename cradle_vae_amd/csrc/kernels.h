@@ -141,11 +141,11 @@ int sum_over_groups_to_cols(const float* da, int groups, int T, int Tc, const in
 int weighted_rowgroup_sum(const float* da, const float* w, int P, int N, int H, float* out, hipStream_t stream);
 int finalize_loss(const float* recon, const float* wrec, const float* ltz, const float* klrow, const float* Smask,
                   const float* SE, const float* Sq, const float* cw, const float* cwq, float beta, int P, int N, int T,
-                  int Q, float* out, hipStream_t stream);
+                  int Q, const int* flags, float* out, hipStream_t stream);
 
 // ---- adam.hip
 int adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int step, float max_norm, float grad_scale, float* norm_ws,
-              hipStream_t stream);
+              const int* skip_flags, hipStream_t stream);
 
 }  // namespace cradle

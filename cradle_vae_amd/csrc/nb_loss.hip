@@ -92,13 +92,15 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
 #pragma unroll
     for (int j = 0; j < VPT; ++j) cur[j] = nxt[j];
     if (p + PS < P) load_row(p + PS, nxt);
-    float2* slot = red[(it & 1) * 3];
+    // three disjoint LDS rows per iteration, alternating between two sets: a fast wave may start the next
+    // reduction while a slow one still reads the previous result, never the one after that
+    const int rbase = (it & 1) * 3;
 
     // row max
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) mx = fmaxf(fmaxf(fmaxf(cur[j].x, cur[j].y), fmaxf(cur[j].z, cur[j].w)), mx);
-    mx = block_max<NT>(mx, reinterpret_cast<float*>(slot));
+    mx = block_max<NT>(mx, reinterpret_cast<float*>(red[rbase]));
     // exp and row sum
     float se = 0.f;
 #pragma unroll
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
       cur[j].w = fast_exp(cur[j].w - mx);
       se += (cur[j].x + cur[j].y) + (cur[j].z + cur[j].w);
     }
-    se = block_sum<NT>(se, reinterpret_cast<float*>(slot + 1));
+    se = block_sum<NT>(se, reinterpret_cast<float*>(red[rbase + 1]));
     const float inv_se = 1.0f / se;
     const float mu_scale = libn * inv_se;  // mu = e * lib / sum(e)
 
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
         if (BWD) usum += (u[j].x + u[j].y) + (u[j].z + u[j].w);
       }
     }
-    const float2 tu = block_sum2<NT>(tsum, usum, slot + 2);
+    const float2 tu = block_sum2<NT>(tsum, usum, red[rbase + 2]);
     if (tid == 0) out[r] = tu.x + LG;
     if (BWD) {
       const float U = tu.y;
@@ -191,23 +193,43 @@ __global__ void nb_gene_consts_kernel(const float* __restrict__ log_c, float* __
   gc[2 * (int64_t)G + g] = (float)ps;
 }
 
-// Deterministic column sum of the (rows, G) partials written by nb_rows_kernel:
-// 16 columns x 64 row slices per block (G/16 blocks: enough to cover the chip at G = 5000).
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part, int rows, int G,
-                                                       float* __restrict__ out, int accumulate) {
-  __shared__ float sm[64][17];
-  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const int col = blockIdx.x * 16 + c;
-  float acc = 0.f;
-  if (col < G)
-    for (int r = rg; r < rows; r += 64) acc += part[(int64_t)r * G + col];
-  sm[rg][c] = acc;
-  __syncthreads();
-  if (rg == 0 && col < G) {
-    float t = 0.f;
+// Deterministic column sum of the (rows, G) partials written by nb_rows_kernel (G % 4 == 0, rows 16-byte
+// aligned).  A workgroup owns 64 columns: 16 lanes x float4 = one 256-byte segment of every row; its 16 row
+// slices (four per wave) walk the rows with independent 16-byte loads, eight in flight per lane, and meet in
+// LDS in a fixed order.  256-thread workgroups on purpose: this runs on a side stream beside the backward
+// pass's GEMMs and has to fit into whatever wave slots they leave free (the 1024-thread form this replaces
+// measured 12 us alone and 170 us inside the step, waiting for whole CUs).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int rows, int G,
+                                                      float* __restrict__ out, int accumulate) {
+  __shared__ float4 sm[16][16];
+  const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int col4 = blockIdx.x * 16 + c;  // float4 column
+  const int G4 = G >> 2;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col4 < G4) {
+    const float4* src = reinterpret_cast<const float4*>(part) + col4;
+    int r = sl;
+    for (; r + 7 * 16 < rows; r += 8 * 16) {
+      float4 v[8];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) t += sm[k][c];
-    out[col] = accumulate ? out[col] + t : t;
+      for (int i = 0; i < 8; ++i) v[i] = src[(int64_t)(r + i * 16) * G4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+    }
+    for (; r < rows; r += 16) {
+      const float4 v = src[(int64_t)r * G4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  sm[sl][c] = acc;
+  __syncthreads();
+  if (sl == 0 && col4 < G4) {
+    float4 t = sm[0][c];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { t.x += sm[k][c].x; t.y += sm[k][c].y; t.z += sm[k][c].z; t.w += sm[k][c].w; }
+    float4* dst = reinterpret_cast<float4*>(out) + col4;
+    if (accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+    *dst = t;
   }
 }
 
@@ -274,7 +296,9 @@ namespace cradle {
 // d loss / d log_concentration: column sums of the `rows` = N * particle_split partial rows the rows
 // kernel left in `workspace`.  Separate from the rows launch so that the step can run it beside the backward.
 int nb_dlogc_reduce(const float* workspace, int rows, int G, float* dlog_c, int accumulate, hipStream_t stream) {
-  hipLaunchKernelGGL(colsum_kernel, dim3((G + 15) / 16), dim3(1024), 0, stream, workspace, rows, G, dlog_c, accumulate);
+  CRADLE_CHECK_ARG(G % 4 == 0 && (uintptr_t)workspace % 16 == 0 && (uintptr_t)dlog_c % 16 == 0,
+                   "nb_dlogc_reduce: G must be a multiple of 4, partials and dlog_concentration 16-byte aligned");
+  hipLaunchKernelGGL(colsum_kernel, dim3((G / 4 + 15) / 16), dim3(256), 0, stream, workspace, rows, G, dlog_c, accumulate);
   CRADLE_CHECK_LAUNCH("colsum_kernel");
   return CRADLE_OK;
 }

@@ -13,10 +13,11 @@
 // impossible by construction; parity tests use sampler = MEAN, moments tests the real sampler.)
 //
 // Two exact samplers of the same distribution.  Marginally x ~ NegBinomial(c, p = rate/(1+rate)):
-//   * rate >= 1/4 (mean <= 4c: almost every gene of a count matrix): inversion by sequential
-//     search from pmf(0) = p^c with pmf(k+1) = pmf(k) (k+c)/(k+1) / (1+rate) -- one uniform, one
-//     log/exp pair, 1 + x iterations; four genes share one Philox call;
-//   * otherwise the Gamma -> Poisson composition the reference's sampler performs.
+//   * rate >= 1/4 and pmf(0) = p^c >= e^-15 (mean <= 37: almost every gene of a count matrix): inversion
+//     by sequential search from pmf(0) with pmf(k+1) = pmf(k) (k+c)/(k+1) / (1+rate) -- one uniform,
+//     one log/exp pair, 1 + x iterations; four genes share one Philox call;
+//   * otherwise (rare, high-mean genes; near-Poisson genes with a large concentration, whose pmf(0) is
+//     below fp32 resolution) the Gamma -> Poisson composition the reference's sampler performs.
 // With workspace, the particles of a condition are split over gridDim.y workgroups whose partial
 // sums are added in a fixed order by a second kernel (a single workgroup per condition leaves the
 // chip almost empty: ~240 conditions per launch).
@@ -112,19 +113,33 @@ __device__ __noinline__ float sample_gamma_poisson(float c, float rate, Philox p
   return sample_poisson(lam, ph, gene, row, draw);
 }
 
-// NegBinomial(c, rate) by inversion; requires rate >= kInvRateMin so that the geometric tail
-// (1+rate)^-k is below fp32 resolution long before the iteration cap.
+// NegBinomial(c, rate) by inversion (sequential search upwards from 0).  Usable where
+//   rate >= kInvRateMin            the geometric tail (1+rate)^-k is below fp32 resolution long before
+//                                  the iteration cap, and
+//   c * log1p(1/rate) <= kInvMaxNegLogP0   pmf(0) = exp(-c log1p(1/rate)) >= 3e-7 is a normal float that the
+//                                  recurrence can climb from with full relative precision.  The two
+//                                  together bound the mean by 15 * 4 / log(5) = 37, so the cap of 512
+//                                  iterations lies > 30 standard deviations out.
+// Everything else (large concentration with a mean in the tens or more: pmf(0) tiny or underflowing)
+// takes the Gamma -> Poisson composition.  nb_inversion_ok() is the routing predicate.
 constexpr float kInvRateMin = 0.25f;
+constexpr float kInvMaxNegLogP0 = 15.0f;
+__device__ __forceinline__ float nb_log1p_inv_rate(float y) {
+  // log1p(y), y = 1/rate: series below 0.03 (log(1+y) would round 1+y first), fast log above
+  return y < 0.03f ? y * (1.0f - y * (0.5f - y * (1.0f / 3.0f))) : __logf(1.0f + y);
+}
+__device__ __forceinline__ bool nb_inversion_ok(float c, float rate) {
+  return rate >= kInvRateMin && c * nb_log1p_inv_rate(__frcp_rn(rate)) <= kInvMaxNegLogP0;
+}
 __device__ __forceinline__ float sample_nb_inversion(float c, float rate, float u) {
   const float y = __frcp_rn(rate);  // 1/rate in (0, 4]
-  // log1p(y): series below 0.03 (log(1+y) would round 1+y first), fast log above
-  const float l1p = y < 0.03f ? y * (1.0f - y * (0.5f - y * (1.0f / 3.0f))) : __logf(1.0f + y);
-  float pk = __expf(-c * l1p);  // pmf(0) = (rate/(1+rate))^c
+  float pk = __expf(-c * nb_log1p_inv_rate(y));  // pmf(0) = (rate/(1+rate))^c >= exp(-15)
   float cdf = pk, k = 0.f;
   if (u > cdf) {
     const float q = y * __frcp_rn(1.0f + y);  // 1/(1+rate)
-    // stop once the increments no longer move the cdf: u is beyond what fp32 resolves
-    while (u > cdf && pk > 1e-9f && k < 512.f) {
+    const float kmode = (c - 1.0f) * y;       // the pmf rises up to here: never stop the search before it
+    // past the mode, stop once the increments no longer move the cdf: u is beyond what fp32 resolves
+    while (u > cdf && (k <= kmode || pk > 1e-9f) && k < 512.f) {
       pk *= (k + c) * q * __frcp_rn(k + 1.0f);
       k += 1.0f;
       cdf += pk;
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
   for (int p = blockIdx.y; p < P; p += gridDim.y, ++it) {
     const int64_t r = (int64_t)p * C + t;
     const float4* L4 = reinterpret_cast<const float4*>(logits + r * ld);
-    float2* slot = red[(it & 1) * 3];
+    const int rbase = (it & 1) * 3;  // disjoint LDS rows per reduction (see nb_loss.hip)
     float4 v[VPT];
     float mx = -INFINITY;
 #pragma unroll
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
       v[j] = k < G4 ? L4[k] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
       mx = fmaxf(fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)), mx);
     }
-    mx = block_max<256>(mx, reinterpret_cast<float*>(slot));
+    mx = block_max<256>(mx, reinterpret_cast<float*>(red[rbase]));
     float se = 0.f;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
       v[j].z = fast_exp(v[j].z - mx); v[j].w = fast_exp(v[j].w - mx);
       se += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     }
-    se = block_sum<256>(se, reinterpret_cast<float*>(slot + 1));
+    se = block_sum<256>(se, reinterpret_cast<float*>(red[rbase + 1]));
     const float mu_scale = libt / se;
     float xs = 0.f;
     const uint32_t row = row_offset + (uint32_t)r;
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
           float x;
           if (sampler == SAMPLER_MEAN) {
             x = cc[q] / rate;
-          } else if (rate >= kInvRateMin) {
+          } else if (nb_inversion_ok(cc[q], rate)) {
             x = sample_nb_inversion(cc[q], rate, u01(ur[q]));
           } else {
             x = sample_gamma_poisson(cc[q], rate, ph, (uint32_t)(k * 4 + q), row);
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
       }
     }
     if (method == METHOD_PERTURBSEQ) {
-      xs = block_sum<256>(xs, reinterpret_cast<float*>(slot + 2));
+      xs = block_sum<256>(xs, reinterpret_cast<float*>(red[rbase + 2]));
       const float sc = 1e4f / xs;  // 0/0 -> NaN like the reference (:174)
 #pragma unroll
       for (int j = 0; j < VPT; ++j) {

@@ -24,77 +24,7 @@
 
 using namespace cradle;
 
-extern "C" {
-
-#define CRADLE_MAX_LAYERS 8
-
-// Pointers of one MLP: trunk layers (W[k]: (H, K_k) row-major, b[k]: (H)) and its output layer
-// (Gaussian heads stacked [mean_encoder; log_var_encoder] as (2L, H) / (2L), or the decoder's
-// normalized_mean_decoder (G, H) / (G)).  Used for parameters and, with the same shapes, gradients.
-struct cradle_mlp_ptrs {
-  int n_layers;
-  float* W[CRADLE_MAX_LAYERS];
-  float* b[CRADLE_MAX_LAYERS];
-  float* W_head;
-  float* b_head;
-};
-
-struct cradle_step_desc {
-  // sizes
-  int P, N, T, L, Q, G, He, Hm, Hd, kmax;
-  // parameters and their gradients (written, not accumulated)
-  float* q_mask_logits;       // (T, L)
-  float* d_q_mask_logits;
-  cradle_mlp_ptrs emb, d_emb;  // embedding encoder  (W[0]: (Hm, L+T))
-  cradle_mlp_ptrs qce, d_qce;  // qc encoder         (W[0]: (Hm, L))
-  cradle_mlp_ptrs enc, d_enc;  // basal encoder      (W[0]: (He, G+2L))
-  cradle_mlp_ptrs dec, d_dec;  // decoder            (W[0]: (Hd, 3L), head: (G, Hd))
-  float* log_concentration;   // (G)
-  float* d_log_concentration;
-  // buffers
-  const float* p_E_loc; const float* p_E_scale; const float* p_mask_probs;  // (T, L)
-  const float* p_qc_E_loc; const float* p_qc_E_scale;                        // (Q, L)
-  const float* log_mean; const float* log_scale;                             // (G)
-  float temperature;
-  // batch
-  const float* X; const float* cfX;  // (N, G)
-  const float* D;                    // (N, T)
-  const float* qc;                   // (N, Q)
-  const float* library_size;         // (N)
-  const float* D_obs_counts;         // (T)
-  const float* qc_obs_counts;        // (Q)
-  // noise: particles [0,P) main guide pass, [P,2P) counterfactual pass
-  const float* u_mask;    // (2P, T, L) uniforms
-  const float* eps_E;     // (2P, T, L)
-  const float* eps_qc_E;  // (2P, Q, L)
-  const float* eps_z;     // (P, N, L)
-  float beta;
-  float alpha;            // < 0: alpha = qc.sum()/N (loss_modules.py:137-139)
-  int compute_grads;      // 0: forward only (validation / test step)
-  // outputs
-  float* out;             // (8): loss, loss_term_{reconstruction,mask,E,qc_E,z_basal}, cf_KLdivergence, -
-  int* flags;             // (1): bit 0 = more than kmax dosages in a cell, bit 1 = qc not binary
-  // scratch
-  void* workspace;
-  int64_t workspace_bytes;
-  // optional profiling: hipEvent_t recorded on the stream right before / after the NB-likelihood
-  // kernels (K1); NULL = off
-  void* ev_k1_begin;
-  void* ev_k1_end;
-  // optional profiling of the largest GEMM (decoder output layer forward, 2*P*N*G*Hd flop): events
-  // recorded on the stream right before / after its launch; NULL = off (ignored by the graphed entry)
-  void* ev_gemm_begin;
-  void* ev_gemm_end;
-  // optional (data-parallel training): events that fire as soon as a bucket of gradients is final,
-  // so that the caller can start reducing it while the rest of the backward pass runs.
-  // [0]: decoder output layer (d_dec.W_head/b_head, d_log_concentration); [1]: the other decoder
-  // gradients; [2]: basal-encoder gradients (d_enc.*).  Everything else is final when the step's work
-  // on `stream` is.  NULL = off; ignored when graphed.
-  void* ev_bucket[3];
-};
-
-}  // extern "C"
-
+// cradle_step_desc / cradle_mlp_ptrs: the one definition lives in the public header (via common.h)
 namespace {
 
 struct Arena {
@@ -489,12 +419,7 @@ int64_t cradle_elbo_step_intermediate(const cradle_step_desc* d, const char* nam
 
 namespace {
 
-// The step in three phases so that the NB-likelihood launch (K1) can sit between two captured
-// graphs when the caller wants HIP events around it (events recorded inside a capture carry no
-// timing).  No side stream is active at either phase boundary.
-enum { PH_PRE = 1, PH_K1 = 2, PH_POST = 4, PH_ALL = 7 };
-
-int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
+int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   const int P = d.P, N = d.N, T = d.T, L = d.L, Q = d.Q, G = d.G, He = d.He, Hm = d.Hm, Hd = d.Hd;
   const int Tc = w.plan.Tc;
   const int PP = 2 * P, PN = P * N, PT = PP * Tc;
@@ -510,7 +435,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
     if (c.rc) return c.rc; \
   } while (0)
 
-  if (phases & PH_PRE) {
+  {
   // ================================================================== forward
   // stream 1: log-standardise X and cfX, x Wx^T.   stream 2: q(qc_E) and the per-gene constants.
   // stream 0 (caller's): dosage plan, q(M), q(E|M), gathers -- then joins both.
@@ -592,8 +517,8 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
   head_fwd(c, d.dec, PN, Hd, G, w.yd[d.dec.n_layers - 1], w.logits);
   if (d.ev_gemm_end) (void)hipEventRecord((hipEvent_t)d.ev_gemm_end, s);
   if (c.rc) return c.rc;
-  }  // PH_PRE
-  if (phases & PH_K1) {
+  }
+  {
   if (!d.compute_grads) {
     if (d.ev_k1_begin) (void)hipEventRecord((hipEvent_t)d.ev_k1_begin, s);
     STEP(cradle_nb_logprob_fwd(w.logits, G, d.X, G, d.library_size, w.gene_consts, w.recon, P, N, G, s));
@@ -603,13 +528,12 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c, int phases) {
                                          w.recon, nullptr, 0, w.nbws, w.nbws_floats, P, N, G, d.ev_k1_begin,
                                          d.ev_k1_end, s));
   }
-  }  // PH_K1
-  if (!(phases & PH_POST)) return CRADLE_OK;
+  }
   // the loss scalars and d log_c are leaves of the graph: stream 2, beside the backward pass
   c.after(2, 0);
   if (d.compute_grads) STEP(nb_dlogc_reduce(w.nbws, N * cradle_nb_particle_split(P, N), G, d.d_log_concentration, 0, s2));
   STEP(finalize_loss(w.recon, w.cp.wrec, w.ltz, w.klrow, w.Smask, w.SE, w.Sq, w.cp.cwc, w.cp.cwq, d.beta, P, N, Tc, Q,
-                     d.out, s2));
+                     d.flags, d.out, s2));
   if (!d.compute_grads) {
     c.after(0, 2);
     return c.rc;
@@ -709,80 +633,6 @@ int prepare(const cradle_step_desc* dp, Work& w, Ctx& c, hipStream_t main) {
   return CRADLE_OK;
 }
 
-// ---- HIP-graph replay of the step ---------------------------------------------------------
-// The step is ~110 launches plus ~40 event operations; enqueueing them costs the host about as
-// long as the GPU needs to run them.  The graphed entry captures the same launch sequence once
-// per distinct descriptor (all pointers, sizes and scalars are baked into the nodes) on a
-// library-owned stream and replays it afterwards.
-constexpr int kGraphSlots = 48;
-// Each slot owns the fork/join events its captures recorded and keeps the captured graphs alive
-// next to their executables: an event recorded during a capture refers to nodes of that graph,
-// so neither is shared with, or outlives into, another capture.
-struct GraphSlot {
-  bool used = false;
-  bool split = false;
-  cradle_step_desc key;
-  hipGraph_t graph[2] = {nullptr, nullptr};
-  hipGraphExec_t exec[2] = {nullptr, nullptr};
-  hipEvent_t ev[kMaxEvents];
-  int nev = 0;
-  uint64_t stamp = 0;
-};
-struct GraphSet {
-  bool ready = false;
-  hipStream_t cs;
-  hipEvent_t ein, eout;
-  GraphSlot slot[kGraphSlots];
-  uint64_t clock = 0;
-};
-GraphSet g_graphs[16];
-
-bool graph_debug() {
-  static const bool on = getenv("CRADLE_GRAPH_DEBUG") != nullptr;
-  return on;
-}
-#define GDBG(...) do { if (graph_debug()) { fprintf(stderr, "[cradle graph] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
-
-// A slot whose capture failed is abandoned, not destroyed, and slots are never evicted: on
-// ROCm 7.2 destroying graph executables that had been launched (hipGraphExecDestroy after a
-// stream synchronise) was followed by a crash inside a later hipGraphLaunch.  The cache is
-// therefore append-only and bounded; once it is full, unknown descriptors launch eagerly.
-void abandon_slot(GraphSlot& sl) {
-  for (int i = 0; i < 2; ++i) sl.exec[i] = nullptr, sl.graph[i] = nullptr;
-  sl.nev = 0;
-  sl.used = false;
-}
-
-int capture(const cradle_step_desc& d, Work& w, Ctx& c, int phases, hipStream_t cs, hipGraph_t* gout,
-            hipGraphExec_t* out) {
-  GDBG("begin capture phases=%d", phases);
-  if (hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) != hipSuccess) {
-    cradle_set_error("elbo_step: hipStreamBeginCapture failed");
-    return CRADLE_ERR_HIP;
-  }
-  const int rc = run_step(d, w, c, phases);
-  hipGraph_t g = nullptr;
-  GDBG("run_step rc=%d, end capture", rc);
-  const hipError_t e = hipStreamEndCapture(cs, &g);
-  GDBG("end capture -> %d graph %p", (int)e, (void*)g);
-  if (rc) {
-    if (g) (void)hipGraphDestroy(g);
-    return rc;
-  }
-  if (e != hipSuccess || !g) {
-    cradle_set_error("elbo_step: hipStreamEndCapture failed: %s", hipGetErrorString(e));
-    return CRADLE_ERR_HIP;
-  }
-  *gout = g;  // owned by the slot from here on
-  const hipError_t ei = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
-  GDBG("instantiate -> %d exec %p", (int)ei, (void*)*out);
-  if (ei != hipSuccess) {
-    cradle_set_error("elbo_step: hipGraphInstantiate failed: %s", hipGetErrorString(ei));
-    return CRADLE_ERR_HIP;
-  }
-  return CRADLE_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -792,87 +642,7 @@ int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
   Ctx c;
   int rc = prepare(dp, w, c, s);
   if (rc) return rc;
-  return run_step(*dp, w, c, PH_ALL);
-}
-
-// Same result as cradle_elbo_step, replayed from a HIP graph.  `*recaptured` (may be NULL) is set
-// to 1 when this call had to capture (first use of this descriptor, or eviction from the 8-slot
-// cache).  With ev_k1_begin/end set, K1 is launched eagerly between two graphs so that the
-// events carry timing.  Not thread-safe; work is ordered after / before the caller's stream `s`.
-int cradle_elbo_step_graphed(const cradle_step_desc* dp, hipStream_t s, int* recaptured) {
-  if (recaptured) *recaptured = 0;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
-    cradle_set_error("elbo_step: cannot identify the current device");
-    return CRADLE_ERR_HIP;
-  }
-  GraphSet& gs = g_graphs[dev];
-  if (!gs.ready) {
-    if (hipStreamCreateWithFlags(&gs.cs, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&gs.ein, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&gs.eout, hipEventDisableTiming) != hipSuccess) {
-      cradle_set_error("elbo_step: graph stream/event creation failed");
-      return CRADLE_ERR_HIP;
-    }
-    gs.ready = true;
-  }
-  Work w;
-  Ctx c;
-  int rc = prepare(dp, w, c, gs.cs);
-  if (rc) return rc;
-  const cradle_step_desc& d = *dp;
-  cradle_step_desc key = d;
-  key.ev_k1_begin = key.ev_k1_end = key.ev_gemm_begin = key.ev_gemm_end = key.ev_bucket[0] = key.ev_bucket[1] = key.ev_bucket[2] = nullptr;
-  cradle_step_desc dg = d;  // events around the GEMM cannot be captured with timing: dropped here
-  dg.ev_gemm_begin = dg.ev_gemm_end = dg.ev_bucket[0] = dg.ev_bucket[1] = dg.ev_bucket[2] = nullptr;
-  const bool split = d.ev_k1_begin || d.ev_k1_end;
-  GraphSlot* sl = nullptr;
-  for (auto& cand : gs.slot)
-    if (cand.used && cand.split == split && memcmp(&cand.key, &key, sizeof(key)) == 0) sl = &cand;
-  if (!sl) {
-    for (auto& cand : gs.slot)
-      if (!cand.used && !cand.exec[0]) { sl = &cand; break; }
-    if (!sl) {  // cache full: launch this descriptor's kernels directly on the caller's stream
-      GDBG("cache full: eager launch");
-      c.st[0] = s;
-      return run_step(dg, w, c, PH_ALL);
-    }
-    for (sl->nev = 0; sl->nev < kMaxEvents; ++sl->nev)
-      if (hipEventCreateWithFlags(&sl->ev[sl->nev], hipEventDisableTiming) != hipSuccess) {
-        abandon_slot(*sl);
-        cradle_set_error("elbo_step: event creation failed");
-        return CRADLE_ERR_HIP;
-      }
-    c.ev = sl->ev;
-    rc = capture(dg, w, c, split ? PH_PRE : PH_ALL, gs.cs, &sl->graph[0], &sl->exec[0]);
-    if (!rc && split) rc = capture(dg, w, c, PH_POST, gs.cs, &sl->graph[1], &sl->exec[1]);
-    if (rc) {
-      abandon_slot(*sl);
-      return rc;
-    }
-    sl->used = true;
-    sl->split = split;
-    sl->key = key;
-    if (recaptured) *recaptured = 1;
-  }
-  sl->stamp = ++gs.clock;
-  GDBG("launch slot %d split=%d", (int)(sl - gs.slot), (int)split);
-  bool ok = hipEventRecord(gs.ein, s) == hipSuccess && hipStreamWaitEvent(gs.cs, gs.ein, 0) == hipSuccess;
-  GDBG("fork ok=%d, launching exec %p", (int)ok, (void*)sl->exec[0]);
-  ok = ok && hipGraphLaunch(sl->exec[0], gs.cs) == hipSuccess;
-  GDBG("launched ok=%d", (int)ok);
-  if (ok && split) {
-    rc = run_step(dg, w, c, PH_K1);
-    if (rc) return rc;
-    ok = hipGraphLaunch(sl->exec[1], gs.cs) == hipSuccess;
-  }
-  ok = ok && hipEventRecord(gs.eout, gs.cs) == hipSuccess && hipStreamWaitEvent(s, gs.eout, 0) == hipSuccess;
-  GDBG("joined ok=%d", (int)ok);
-  if (!ok) {
-    cradle_set_error("elbo_step: graph launch failed: %s", hipGetErrorString(hipGetLastError()));
-    return CRADLE_ERR_HIP;
-  }
-  return CRADLE_OK;
+  return run_step(*dp, w, c);
 }
 
 }  // extern "C"

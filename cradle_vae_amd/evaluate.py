@@ -49,13 +49,13 @@ def evaluate_module(lightning_module, data_module, average_treatment_effect_meth
 
 def evaluate_checkpoint(checkpoint_path: str, average_treatment_effect_method: Literal["mean", "perturbseq"],
                         batch_size: int = 500, ate_n_particles: int = 2500, qc_pass: bool = False, thr: int = 5,
-                        devices=None, data_module: Optional[Any] = None, trusted: bool = False) -> Dict[str, Any]:
+                        devices=None, data_module: Optional[Any] = None) -> Dict[str, Any]:
     """eval.py:41-129 with the same leading arguments; ``data_module`` may be passed instead of being
     rebuilt from the checkpoint's config."""
     from .lightning_module import load_checkpoint
 
     device = f"cuda:{devices[0] if isinstance(devices, (list, tuple)) else (devices or 0)}"
-    module = load_checkpoint(checkpoint_path, map_location=device, trusted=trusted)
+    module = load_checkpoint(checkpoint_path, map_location=device)
     if data_module is None:
         data_module = module.get_data_module()
     return evaluate_module(module, data_module, average_treatment_effect_method, batch_size, ate_n_particles, qc_pass)

@@ -23,6 +23,7 @@ PROTOTYPES = {
     "cradle_last_error": (ctypes.c_char_p, []),
     "cradle_abi_version": (i32, []),
     "cradle_device_count": (i32, []),
+    "cradle_struct_layout": (i32, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), i32]),
     "cradle_event_create": (i32, [ctypes.POINTER(ctypes.c_void_p)]),
     "cradle_event_destroy": (i32, [ctypes.c_void_p]),
     "cradle_event_elapsed_ms": (i32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
@@ -49,11 +50,10 @@ PROTOTYPES = {
     "cradle_elbo_step_workspace_bytes": (i64, [ctypes.c_void_p]),
     "cradle_elbo_step": (i32, [ctypes.c_void_p, c_stream]),
     "cradle_elbo_step_intermediate": (i64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
-    "cradle_elbo_step_graphed": (i32, [ctypes.c_void_p, c_stream, ctypes.POINTER(ctypes.c_int)]),
     "cradle_adam_step": (
         i32,
         [c_float_p, c_float_p, c_float_p, c_float_p, i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-         ctypes.c_float, ctypes.c_float, i32, ctypes.c_float, ctypes.c_float, c_float_p, c_stream],
+         ctypes.c_float, ctypes.c_float, i32, ctypes.c_float, ctypes.c_float, c_float_p, ctypes.c_void_p, c_stream],
     ),
     "cradle_adam_workspace_floats": (i64, []),
     "cradle_nb_sample_accumulate_ws": (
@@ -70,6 +70,7 @@ PROTOTYPES = {
 }
 
 MAX_LAYERS = 8
+ABI_VERSION = 2
 
 
 class MlpPtrs(ctypes.Structure):
@@ -147,8 +148,29 @@ def load() -> ctypes.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
+    if lib.cradle_abi_version() != ABI_VERSION:
+        raise CradleHipError(f"{_LIB_PATH} has ABI version {lib.cradle_abi_version()}, this binding expects "
+                             f"{ABI_VERSION}: rebuild it (make -C cradle_vae_amd/csrc)")
+    for cname, cls in (("cradle_mlp_ptrs", MlpPtrs), ("cradle_gemm_desc", GemmDesc), ("cradle_step_desc", StepDesc)):
+        mine, theirs = struct_layout(cls), library_struct_layout(lib, cname)
+        if mine != theirs:
+            raise CradleHipError(f"layout of {cname} differs between include/cradle_hip.h as compiled "
+                                 f"({theirs}) and cradle_vae_amd/hip.py ({mine})")
     _lib = lib
     return lib
+
+
+def struct_layout(cls) -> list:
+    """[sizeof, offsetof(field) ...] of a ctypes mirror, in declaration order."""
+    return [ctypes.sizeof(cls)] + [getattr(cls, name).offset for name, *_ in cls._fields_]
+
+
+def library_struct_layout(lib, name: str) -> list:
+    buf = (ctypes.c_int64 * 128)()
+    n = lib.cradle_struct_layout(name.encode(), buf, 128)
+    if n <= 0:
+        raise CradleHipError(f"cradle_struct_layout({name!r}) failed")
+    return list(buf[:n])
 
 
 def check(rc: int, what: str):

@@ -251,10 +251,6 @@ def _restore_config(config: Dict) -> Dict:
     if isinstance(stats, dict):
         gk["x_normalization_stats"] = ObservationNormalizationStatistics(
             **{k: v for k, v in stats.items() if k != "__stats__"})
-    elif stats is not None and not isinstance(stats, ObservationNormalizationStatistics):
-        # a reference checkpoint unpickled by a trusted load: same field names
-        gk["x_normalization_stats"] = ObservationNormalizationStatistics(
-            **{k: getattr(stats, k, None) for k in ("x_mean", "x_std", "log_x_mean", "log_x_std")})
     cfg["guide_kwargs"] = gk
     return cfg
 
@@ -268,11 +264,13 @@ def save_checkpoint(module: "TrainConfigPerturbationLightningModule", path: str,
     torch.save(ckpt, path)
 
 
-def load_checkpoint(path: str, map_location=None, trusted: bool = False) -> "TrainConfigPerturbationLightningModule":
-    """Rebuilds the module from a checkpoint written by ``save_checkpoint`` (or, with
-    ``trusted=True``, by Lightning for the reference: that one unpickles arbitrary objects, so only
-    pass ``trusted`` for files you produced)."""
-    ckpt = torch.load(path, map_location="cpu", weights_only=not trusted)
+def load_checkpoint(path: str, map_location=None) -> "TrainConfigPerturbationLightningModule":
+    """Rebuilds the module from a checkpoint written by ``save_checkpoint``.  Always loaded with
+    ``weights_only=True``: nothing in the file is executed.  A checkpoint Lightning wrote for the reference
+    pickles its config objects (a dataclass of tensors, a pandas Index) and is refused by that loader; convert
+    it once, offline and explicitly, in an environment that trusts the file -- read it there, keep
+    ``state_dict`` and the plain config, and write them with ``save_checkpoint``'s layout."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
     hp = ckpt["hyper_parameters"]
     sd = ckpt["state_dict"]
     config = _restore_config(hp["config"])
@@ -294,5 +292,4 @@ def load_checkpoint(path: str, map_location=None, trusted: bool = False) -> "Tra
 
 if not HAVE_LIGHTNING:
     TrainConfigPerturbationLightningModule.load_from_checkpoint = classmethod(
-        lambda cls, checkpoint_path, map_location=None, trusted=False, **kw: load_checkpoint(
-            checkpoint_path, map_location, trusted))
+        lambda cls, checkpoint_path, map_location=None, **kw: load_checkpoint(checkpoint_path, map_location))

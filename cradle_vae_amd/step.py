@@ -152,43 +152,27 @@ class FusedElboStep:
         # hip.EventPair whose two events fire when the decoder / basal-encoder gradients are final
         # (trainer.TrainStep starts their all-reduce while the rest of the backward pass runs)
         self.bucket_events = None
-        # Optional HIP-graph replay (cradle_elbo_step_graphed).  Off by default: on ROCm 7.2 / MI355X
-        # the replay of this multi-branch graph measured slower (1.52 ms) than launching its kernels
-        # on three streams (1.35 ms) -- the step is GPU-bound, not enqueue-bound.  The graph bakes every
-        # pointer in, so batches arriving at changing addresses are first copied into persistent
-        # staging buffers (switched on automatically once re-captures keep happening).
-        self.use_graph = False
-        self.stage_inputs = False
-        self._staged = None
-        self._recaptures = 0
+        self._checked_states = set()
 
     # ------------------------------------------------------------------ descriptor
     def _select_state(self, P, N):
-        """Per-(P, N) descriptor, outputs, noise and staging buffers are kept, so that alternating
-        shapes (training / validation batches) come back to the pointers their graphs were captured with."""
+        """Per-(P, N) descriptor, outputs and noise buffers are kept, so that alternating shapes
+        (training / validation batches) do not rebuild them."""
         key = (P, N, self.arena.base)
         st = self._states.get(key)
         if st is None:
             if len(self._states) >= 4:
                 self._states.pop(next(iter(self._states)))
             self.desc = hip.StepDesc()
-            self._staged = None
             self._fill_static(P, N)
-            st = dict(desc=self.desc, out=self.out, flags=self.flags, noise=self._noise, bufs=self._bufs, staged=None)
+            st = dict(desc=self.desc, out=self.out, flags=self.flags, noise=self._noise, bufs=self._bufs)
             self._states[key] = st
         else:
-            if self._shape_key != key:
-                self._states_save()
-            self.desc, self.out, self.flags, self._noise, self._bufs, self._staged = (
-                st["desc"], st["out"], st["flags"], st["noise"], st["bufs"], st["staged"])
+            self.desc, self.out, self.flags, self._noise, self._bufs = (
+                st["desc"], st["out"], st["flags"], st["noise"], st["bufs"])
         self._shape_key = key
         if self.desc.workspace != self.workspace.data_ptr():  # the shared workspace grew meanwhile
             self.desc.workspace, self.desc.workspace_bytes = self.workspace.data_ptr(), self.workspace.numel() * 4
-
-    def _states_save(self):
-        st = self._states.get(self._shape_key)
-        if st is not None:
-            st["staged"] = self._staged
 
     def _fill_static(self, P, N):
         lm, d, a = self.lm, self.desc, self.arena
@@ -256,20 +240,12 @@ class FusedElboStep:
             self._states.clear()
             self._shape_key = None
         P, N = n_particles, X.shape[0]
-        self._states_save()
         self._select_state(P, N)
         d = self.desc
         if X.shape[1] != d.G or D.shape != (N, d.T) or qc.shape != (N, d.Q) or cfX.shape != X.shape:
             raise hip.CradleHipError("elbo_step: batch tensor shapes do not match the model")
         ins = (X, cfX, D, qc, library_size.reshape(-1), D_obs_counts, qc_obs_counts)
-        if self.use_graph and self.stage_inputs:
-            if self._staged is None or any(a.shape != b.shape for a, b in zip(self._staged, ins)):
-                self._staged = [torch.empty(t.shape, device=X.device, dtype=torch.float32) for t in ins]
-            for dst, src in zip(self._staged, ins):
-                dst.copy_(src)
-            self._keep = self._staged
-        else:
-            self._keep = [t.contiguous().float() for t in ins]
+        self._keep = [t.contiguous().float() for t in ins]
         (d.X, d.cfX, d.D, d.qc, d.library_size, d.D_obs_counts, d.qc_obs_counts) = [hip.ptr(t) for t in self._keep]
         self._set_noise(noise, cf_noise, gen_plated, gen_local)
         d.beta = float(self.lm.beta)
@@ -282,27 +258,23 @@ class FusedElboStep:
             d.ev_k1_begin, d.ev_k1_end = ev.begin, ev.end
         else:
             d.ev_k1_begin, d.ev_k1_end = None, None
-        be = self.bucket_events if (compute_grads and not self.use_graph) else None
+        be = self.bucket_events if compute_grads else None
         for i in range(3):  # bucket_events: two hip.EventPair = (out layer, decoder) and (basal encoder, unused)
             d.ev_bucket[i] = None if be is None else (be[0].begin, be[0].end, be[1].begin)[i]
-        if self.gemm_events is not None and not self.use_graph and sample:
+        if self.gemm_events is not None and sample:
             ev = hip.EventPair()
             self.gemm_events.append(ev)
             d.ev_gemm_begin, d.ev_gemm_end = ev.begin, ev.end
         else:
             d.ev_gemm_begin, d.ev_gemm_end = None, None
-        if self.use_graph:
-            recaptured = ctypes.c_int(0)
-            hip.check(self.lib.cradle_elbo_step_graphed(ctypes.byref(d), hip.stream(), ctypes.byref(recaptured)),
-                      "cradle_elbo_step_graphed")
-            if recaptured.value:
-                self._recaptures += 1
-                if self._recaptures >= 6 and not self.stage_inputs:
-                    self.stage_inputs = True  # input addresses keep changing: pin them
-        else:
-            hip.check(self.lib.cradle_elbo_step(ctypes.byref(d), hip.stream()), "cradle_elbo_step")
+        hip.check(self.lib.cradle_elbo_step(ctypes.byref(d), hip.stream()), "cradle_elbo_step")
         self._calls += 1
-        if self._calls == 1 or self._calls % 256 == 0:
+        # A rejected input (flags != 0) is harmless on the device: the step's loss is NaN and cradle_adam_step,
+        # handed the same flags word, skips its update.  The host only has to say why, which costs a sync: on
+        # the first call of every (P, N) state (a new loader), every 256th call, in forward-only (validation /
+        # test) calls, and whenever trainer.fit finishes an epoch (check_flags).
+        if self._shape_key not in self._checked_states or self._calls % 256 == 0 or not compute_grads:
+            self._checked_states.add(self._shape_key)
             self.check_flags()
         return self.out
 
@@ -318,7 +290,16 @@ class FusedElboStep:
         return self.workspace[off:off + n].clone()
 
     def check_flags(self):
-        f = int(self.flags.item())
+        """Raises if the last step -- or, by the sticky count in out[7], any step since the last look -- rejected
+        its input.  Synchronises."""
+        f, rejected = int(self.flags.item()), float(self.out[7].item())
+        if rejected and not f:
+            self.out[7] = 0.0
+            raise hip.CradleHipError(
+                f"{int(rejected)} earlier step(s) rejected their input (a cell with more than kmax={self.desc.kmax} "
+                "non-zero dosages, or qc outside {0,1}); their loss was NaN and their parameter update was skipped")
+        if f:
+            self.out[7] = 0.0
         if f & 1:
             raise hip.CradleHipError(f"a cell has more than kmax={self.desc.kmax} non-zero dosages: raise kmax")
         if f & 2:

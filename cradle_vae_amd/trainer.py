@@ -68,7 +68,7 @@ class TrainStep:
             qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
             n_particles=n_particles, gen_plated=self.gen_plated, gen_local=self.gen_local)
         a = f.arena
-        if self.world_size > 1 and self.overlap and not f.use_graph:
+        if self.world_size > 1 and self.overlap:
             self._bucketed_allreduce(a)
         else:
             parallel.allreduce_sum_(a.grad, self.world_size)  # one RCCL call on the flat gradient arena; averaged inside Adam
@@ -78,7 +78,7 @@ class TrainStep:
                 a.flat.data_ptr(), a.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), a.numel,
                 self.lr, 0.9, 0.999, 1e-8, self.weight_decay, self.step_count,
                 float(self.clip) if self.clip is not None else -1.0, 1.0 / self.world_size, self.norm_ws.data_ptr(),
-                hip.stream()),
+                f.flags.data_ptr(), hip.stream()),
             "cradle_adam_step")
         self.last_out = out
         return out[0]
@@ -166,6 +166,8 @@ def fit(module, train_loader, val_loader=None, *, max_epochs: int = 1, max_steps
                 print(f"epoch {epoch} step {steps} train/loss {float(loss):.4f}", flush=True)
             if max_steps is not None and steps >= max_steps:
                 break
+        if stepper.fused is not None:
+            stepper.fused.check_flags()  # no epoch ends with a rejected batch unreported
         record = {"epoch": epoch, "steps": steps, "train/loss": float(tot / max(cnt, 1)) if tot is not None else None}
         if val_loader is not None:
             module.eval()

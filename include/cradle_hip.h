@@ -38,6 +38,11 @@ typedef struct ihipStream_t* cradle_stream_t; /* == hipStream_t */
 const char* cradle_last_error(void);
 int cradle_abi_version(void);
 int cradle_device_count(void);
+/* Layout of a descriptor struct ("cradle_step_desc", "cradle_gemm_desc", "cradle_mlp_ptrs") as the library
+ * was compiled: out[0] = sizeof, out[1..] = offsetof of every field in declaration order; returns the number
+ * of entries written, -1 for an unknown name or a short buffer.  Bindings that mirror the structs check
+ * themselves against it at load time (cradle_vae_amd/hip.py). */
+int cradle_struct_layout(const char* name, int64_t* out, int max_entries);
 /* hipEvent helpers for hosts without their own HIP binding (bench.py) */
 int cradle_event_create(void** ev);
 int cradle_event_destroy(void* ev);
@@ -68,8 +73,8 @@ int cradle_nb_logprob_fwd(const float* logits, int64_t ld_logits, const float* X
 
 /* Forward + backward in one pass over the logits (training).  `grow` (P*N) is d loss/d out.
  * dlogits (may alias logits: each row is overwritten after it was read) receives
- * d loss/d logits; dlog_concentration (G) receives (accumulate=0) or is incremented by
- * (accumulate=1) d loss/d log_concentration.  workspace: cradle_nb_workspace_floats floats. */
+ * d loss/d logits; dlog_concentration (G, 16-byte aligned) receives (accumulate=0) or is incremented by
+ * (accumulate=1) d loss/d log_concentration.  workspace: cradle_nb_workspace_floats floats, 16-byte aligned. */
 int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
                               const float* X, int64_t ldx, const float* library, const float* gene_consts,
                               const float* grow, float* out, float* dlog_concentration, int accumulate,
@@ -134,7 +139,8 @@ int cradle_gemm_f32_repeat(const cradle_gemm_desc* desc, float* workspace, int64
  * log-ratio terms :153-177,200-232, loss :179-181) including everything it calls:
  * correlated_normal_guide.py:102-209, model.py:59-129, mlp.py:111-168, normalization.py:41-45,
  * gumbel_softmax_bernoulli.py:5-17 -- and of the autograd backward Lightning runs after it.
- * One stream-ordered sequence of kernels; nothing allocates or synchronises.
+ * Kernels on the caller's stream and two library-owned side streams joined back before return (fork/join by
+ * events); nothing allocates or synchronises with the host.
  * Restrictions (every shipped config satisfies them): sum_mode=False, mean_field_encoder=False,
  * log_standardize input normalisation, library_nb likelihood, qc entries in {0,1}, at most
  * `kmax` non-zero dosages per cell.  Violations of the last two raise bits in *flags. */
@@ -175,20 +181,24 @@ typedef struct cradle_step_desc {
   float beta;
   float alpha;            /* < 0: alpha = qc.sum()/N (loss_modules.py:137-139) */
   int compute_grads;      /* 0: forward only */
-  float* out;             /* (8): loss, loss_term_{reconstruction,mask,E,qc_E,z_basal}, cf_KLdivergence, unused */
-  int* flags;             /* (1) */
+  float* out;             /* (8): loss, loss_term_{reconstruction,mask,E,qc_E,z_basal}, cf_KLdivergence, and [7] += 1
+                             for every step whose input was rejected (the caller zeroes it; the loss of such a
+                             step is NaN) */
+  int* flags;             /* (1) written by every step: bit 0 = a cell with more than kmax non-zero dosages (or more
+                             treatments present than compact slots), bit 1 = a qc entry outside {0,1}; non-zero =
+                             loss and gradients of this step are not valid (hand the word to cradle_adam_step) */
   void* workspace;
   int64_t workspace_bytes;
   void* ev_k1_begin;      /* optional hipEvent_t recorded before / after the K1 launches; NULL = off */
   void* ev_k1_end;
   void* ev_gemm_begin;    /* optional hipEvent_t recorded before / after the largest GEMM of the step (decoder */
-  void* ev_gemm_end;      /* output layer forward, 2*P*N*G*Hd flop); NULL = off; ignored by the graphed entry */
+  void* ev_gemm_end;      /* output layer forward, 2*P*N*G*Hd flop); NULL = off */
   void* ev_bucket[3];     /* optional hipEvent_t fired as soon as a gradient bucket is final (replaces DDP's
                              bucketed backward hooks under Lightning's ddp strategy, train_norman.py:89-97):
                              [0] the decoder's output layer (d_dec.W_head, d_dec.b_head, d_log_concentration:
                              a third of all parameters, final first), [1] the other decoder gradients,
                              [2] basal-encoder gradients (d_enc.*); the rest is final with the step.
-                             NULL = off; ignored when graphed */
+                             NULL = off */
 } cradle_step_desc;
 
 int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only the sizes are read */
@@ -198,23 +208,17 @@ int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only 
  * the decoder input of model.py:121), "logits" (P*N*G).  Returns the element count, or -1. */
 int64_t cradle_elbo_step_intermediate(const cradle_step_desc* desc, const char* name, const float** ptr);
 int cradle_elbo_step(const cradle_step_desc* desc, cradle_stream_t stream);
-/* Same result, replayed from a HIP graph: the ~110 launches of the step are captured once per
- * distinct descriptor (every pointer, size and scalar is baked into the graph; up to 48 descriptors
- * are kept per device, never evicted -- beyond that, unknown descriptors launch eagerly) on a
- * library-owned stream ordered after/before `stream`.  *recaptured (may
- * be NULL) reports whether this call had to capture.  With ev_k1_begin/end set, K1 is launched
- * eagerly between two graphs so that the events carry timing.  Not thread-safe. */
-int cradle_elbo_step_graphed(const cradle_step_desc* desc, cradle_stream_t stream, int* recaptured);
-
 /* ---- K10: gradient-norm clip + Adam over flat arenas -----------------------------------
  * Replaces Lightning's gradient_clip_val (train_norman.py:96; torch clip_grad_norm_) followed by
  * torch.optim.Adam(lr, weight_decay) (perturbation_lightning_module.py:147-150).
  * g' = grads * grad_scale; coef = max_norm > 0 ? min(1, max_norm / (|g'| + 1e-6)) : 1;
  * then Adam with L2 weight decay on g' * coef.  norm_ws: cradle_adam_workspace_floats() floats;
- * its last element receives |g'|. */
+ * its last element receives |g'|.  skip_flags: NULL, or a device int (cradle_step_desc.flags of the step
+ * that produced `grads`): when it is non-zero the update is skipped -- parameters and moments stay as they
+ * are -- so gradients of a rejected input never reach the parameters, whenever the host gets to look. */
 int cradle_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
-                     float grad_scale, float* norm_ws, cradle_stream_t stream);
+                     float grad_scale, float* norm_ws, const int* skip_flags, cradle_stream_t stream);
 int64_t cradle_adam_workspace_floats(void);
 
 /* ---- K9: Gamma-Poisson observation sampler fused with the ATE accumulation ---------------

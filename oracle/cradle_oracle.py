@@ -359,12 +359,29 @@ def elbo_loss(
     n_particles: int,
     beta: float = 1.0,
     alpha: Optional[float] = None,
+    as_written: bool = False,
 ) -> Tuple[Tensor, Dict[str, Tensor], Dict[str, Tensor]]:
     """PerturbationPlatedELBOLossModule.loss (loss_modules.py:110-187) with
-    .forward (:54-106) inlined.  Returns (loss, metrics, intermediates)."""
+    .forward (:54-106) inlined.  Returns (loss, metrics, intermediates).
+
+    ``as_written`` (timing only, bench.py's cpu_baseline): also does the work the reference does and
+    throws away -- the x_good / x_bad Gamma -> Poisson draws of model.py:131-132 (pyro
+    GammaPoisson.sample = Poisson(Gamma(c, rate).sample()).sample()) and the argument / support checks
+    torch.distributions runs with validate_args on (its default in the reference).  The loss is the same."""
     P = n_particles
     g_d, g_s = guide_forward(params, noise, P, X=X, D=D, qc=qc)  # :69-74
     c, rate_good, rate_bad = model_decode(params, D, qc, g_s, library_size)  # :88-93
+    if as_written:
+        with torch.no_grad():
+            for rate in (rate_good, rate_bad):  # model.py:131-132
+                assert bool((c > 0).all()) and bool((rate > 0).all())  # GammaPoisson arg_constraints
+                lam = torch._standard_gamma(c.expand_as(rate).contiguous()) / rate
+                assert bool((lam >= 0).all())  # Poisson(rate) arg constraint
+                torch.poisson(lam)
+            assert bool(((X >= 0) & (X == X.round())).all())  # GammaPoisson.support in log_prob, twice (:134-135)
+            assert bool(((X >= 0) & (X == X.round())).all())
+            for k in ("q_E_std", "q_qc_E_std", "q_z_basal_std", "q_z_cf_basal_std"):  # Normal(scale > 0)
+                assert bool((g_d[k] > 0).all())
     cf_d, cf_s = guide_forward(params, cf_noise, P, X=cfX, D=D, qc=1 - qc)  # :97-102
 
     logp_good = gamma_poisson_log_prob(X, c, rate_good)  # :134

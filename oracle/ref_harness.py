@@ -1,8 +1,8 @@
 """Runs the reference's own hot-path modules (read from /root/reference) on CPU.
 
 TEST INFRASTRUCTURE ONLY, and only usable in the build container: the GPU box has no
-/root/reference.  Used by ``oracle/make_golden.py`` to produce ``tests/golden/*.npz`` and
-by ``tests/test_oracle_vs_reference.py`` (skipped where the reference is absent).
+/root/reference.  Used by ``oracle/make_golden.py`` to produce ``tests/golden/*.npz`` (the
+fixtures ``tests/test_oracle_golden.py`` then pins the oracle to, wherever it runs).
 
 The reference imports packages that are not installed anywhere in this pipeline
 (pyro, pytorch_lightning, anndata, scanpy, rapids_singlecell, cupy, wandb).  They are

@@ -22,7 +22,31 @@ def test_library_exports_every_declared_symbol():
         assert name in hip.PROTOTYPES, f"{name} has no ctypes prototype in cradle_vae_amd/hip.py"
     for name in hip.PROTOTYPES:
         assert name in names, f"{name} bound in hip.py but not declared in the header"
-    assert lib.cradle_abi_version() == 1
+    assert lib.cradle_abi_version() == hip.ABI_VERSION
+
+
+def test_descriptor_layouts_agree_between_header_library_and_binding():
+    """include/cradle_hip.h is the one definition of the descriptor structs (the .hip files include it); the
+    ctypes mirrors in hip.py must have the same size and field offsets as the compiled library reports, and as
+    many fields as the header declares."""
+    lib = hip.load()
+    text = open(os.path.join(ROOT, "include", "cradle_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for cname, cls in (("cradle_mlp_ptrs", hip.MlpPtrs), ("cradle_gemm_desc", hip.GemmDesc),
+                       ("cradle_step_desc", hip.StepDesc)):
+        mine, theirs = hip.struct_layout(cls), hip.library_struct_layout(lib, cname)
+        assert mine == theirs, (cname, mine, theirs)
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
+        declared = 0
+        for stmt in body.split(";"):
+            stmt = stmt.strip()
+            if stmt:
+                declared += stmt.count(",") + 1
+        assert declared == len(cls._fields_), (cname, declared, len(cls._fields_))
+    for src in ("step.hip", "gemm.hip"):  # no second definition anywhere in the sources
+        code = open(os.path.join(ROOT, "cradle_vae_amd", "csrc", src)).read()
+        assert "struct cradle_step_desc {" not in code and "struct cradle_gemm_desc {" not in code
+    assert lib.cradle_struct_layout(b"nonsense", (hip.ctypes.c_int64 * 4)(), 4) == -1
 
 
 def test_host_side_helpers_need_no_gpu():

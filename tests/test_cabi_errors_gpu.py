@@ -41,7 +41,7 @@ def test_sampler_and_adam_reject_bad_arguments():
     assert rc != 0 and b"library" in lib.cradle_last_error()  # 1 or C library sizes
     p = torch.zeros(16, device=DEV)
     rc = lib.cradle_adam_step(hip.ptr(p), hip.ptr(p), hip.ptr(p), hip.ptr(p), 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 100.0, 1.0,
-                              hip.ptr(p), hip.stream())
+                              hip.ptr(p), None, hip.stream())
     assert rc != 0  # step counts from 1
 
 

@@ -1,0 +1,61 @@
+"""The fused HIP ELBO step at BASELINE.json's full sizes against the CPU oracle (fp64): the Norman demo
+shape (N=512, P=5, G=5000, T=105, L=200, H=400 -- the shape bench.py's metric is quoted on) and a
+Replogle-like shape (G=8000, T=2000, L=100, compact treatment axis).  The golden fixtures stop at
+N=64, G=300, H=32; this is the same comparison where the kernels run the tile shapes, split-K factors and
+particle splits they run in production.  Bars: loss and every loss term <= 1e-4 relative (north_star),
+every parameter gradient <= 2e-3 of its largest entry and <= 1e-4 in relative L2."""
+import dataclasses
+
+import pytest
+import torch
+
+from tests.test_fused_step_gpu import run_fused
+from tests.test_modular_gpu import DEV, GRAD_L2_RTOL, build_loss_module
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,kmax", [("norman", 2), ("replogle", 2)])
+def test_fused_step_matches_oracle_at_full_size(name, kmax):
+    from cradle_vae_amd import synthetic as syn
+    from oracle import cradle_oracle as co
+
+    shape = syn.SHAPES[name]
+    b = syn.make_batch(shape, seed=17)
+    cfg = dict(
+        n_latent=shape.n_latent, n_treatments=shape.n_treatments, n_phenos=shape.n_phenos, n_qc=shape.n_qc,
+        decoder_n_layers=shape.decoder_n_layers, decoder_n_hidden=shape.decoder_n_hidden,
+        basal_encoder_n_layers=shape.basal_encoder_n_layers, basal_encoder_n_hidden=shape.basal_encoder_n_hidden,
+        embedding_encoder_n_layers=shape.embedding_encoder_n_layers,
+        embedding_encoder_n_hidden=shape.embedding_encoder_n_hidden, mask_prior_prob=shape.mask_prior_prob,
+        embedding_prior_scale=1.0, beta=shape.beta, alpha=None, n_particles=shape.n_particles)
+    params = co.init_params(**{k: cfg[k] for k in cfg if k not in ("beta", "alpha", "n_particles")},
+                            log_x_mean=b["log_x_mean"], log_x_std=b["log_x_std"], seed=23)
+    noise, cf_noise = syn.make_noise(shape, 31), syn.make_noise(shape, 32)
+    f64 = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
+    torch.set_num_threads(16)
+    ref_loss, ref_metrics, _, ref_grads = co.elbo_loss_and_grads(
+        f64(params), X=b["X"].double(), D=b["D"].double(), qc=b["qc"].double(), cfX=b["cfX"].double(),
+        library_size=b["library_size"].double(), D_obs_counts=b["D_obs_counts"].double(),
+        qc_obs_counts=b["qc_obs_counts"].double(), noise=f64(noise), cf_noise=f64(cf_noise),
+        n_particles=cfg["n_particles"], beta=cfg["beta"], alpha=cfg["alpha"])
+    assert torch.isfinite(ref_loss)
+
+    dev = lambda d: {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in d.items()}
+    case = dict(cfg=cfg, params=dev(params), batch=dev(b), noise=dev(noise), cf_noise=dev(cf_noise))
+    lm = build_loss_module(case)
+    lm.max_dosages_per_cell = kmax
+    loss, metrics, grads = run_fused(lm, case)
+    d = lm._fused.desc
+    assert (d.N * d.kmax < d.T) == (name == "replogle")  # Replogle runs the compact treatment axis
+
+    rtol = 1e-4
+    assert abs(float(loss.detach()) - float(ref_loss)) <= rtol * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    for k, v in ref_metrics.items():
+        assert abs(float(metrics[k]) - float(v)) <= rtol * max(1.0, abs(float(v))), (k, float(metrics[k]), float(v))
+    for k, g in ref_grads.items():
+        got = grads[k].detach().cpu().double()
+        err = float((got - g).abs().max()) / max(float(g.abs().max()), 1e-12)
+        assert err <= 2e-3, (k, err)
+        l2 = float((got - g).norm()) / max(float(g.norm()), 1e-12)
+        assert l2 <= GRAD_L2_RTOL, (k, l2)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from tests.test_fused_step_gpu import run_fused
-from tests.test_modular_gpu import DEV, build_loss_module
+from tests.test_modular_gpu import DEV, GRAD_L2_RTOL, build_loss_module
 
 pytestmark = pytest.mark.gpu
 
@@ -80,3 +80,5 @@ def test_fused_step_matches_oracle_on_ragged_shapes(name):
         got = grads[k].detach().cpu().double()
         err = float((got - g).abs().max()) / max(float(g.abs().max()), 1e-8)
         assert err <= 2e-3, (k, err)
+        l2 = float((got - g).norm()) / max(float(g.norm()), 1e-12)
+        assert l2 <= GRAD_L2_RTOL, (k, l2)

@@ -177,6 +177,51 @@ def test_sampler_large_rates_and_determinism():
     assert float(rel.median()) < 0.1, float(rel.median())
 
 
+def test_sampler_high_concentration_near_poisson_genes():
+    """Concentrations of 12-150 with means of 20-500 (trained near-Poisson genes) on the rate >= 1/4 side:
+    pmf(0) = (rate/(1+rate))^c is far below fp32 resolution there, so a search upwards from 0 must not be
+    cut off before the mode (it returned 0 for every draw once).  Moments and pmf against scipy."""
+    from scipy.stats import nbinom
+
+    from cradle_vae_amd import ops
+
+    P, C, G = 8192, 2, 64
+    g = torch.Generator().manual_seed(21)
+    log_c = 2.5 + 2.5 * torch.rand(G, generator=g)
+    c = log_c.double().exp()
+    # target means in [20, 500], capped at 3.9 c so that rate = c / mean stays >= 1/4 (second condition: half of that)
+    mean_t = torch.minimum(20.0 + 480.0 * torch.rand(C, G, generator=g).double(), 3.9 * c)
+    mean_t[1] = torch.clamp(0.5 * mean_t[1], min=15.0)
+    lib = mean_t.sum(-1)
+    logits = mean_t.log().float().repeat(P, 1).contiguous().to(DEV)  # softmax * lib = the target means
+    consts = ops.nb_gene_consts(log_c.to(DEV))
+    _, x = ops.nb_sample_accumulate(logits, lib.float().to(DEV), consts, P, C, seed=4321, return_samples=True)
+    x = x.reshape(P, C, G).double().cpu()
+    c32 = log_c.exp().double()
+    mu = lib.float().double().reshape(C, 1) * torch.softmax(logits[:C].double().cpu(), -1)
+    rate = torch.clamp(c32 / (mu + 1e-4), min=1e-6)
+    assert float(rate.min()) >= 0.25
+    mean, var = c32 / rate, c32 / rate**2 * (1 + rate)
+    assert float(x.mean(0).min()) > 10.0  # the failure mode: all-zero draws
+    z = (x.mean(0) - mean) / (var / P).sqrt()
+    assert float(z.abs().max()) < 5.0, float(z.abs().max())
+    rel = (x.var(0) - var).abs() / var
+    assert float(rel.median()) < 0.05 and float(rel.max()) < 0.2, (float(rel.median()), float(rel.max()))
+    for (t, gi) in [(0, 0), (0, int(c32.argmax())), (1, int(c32.argmin())), (1, int(mean[1].argmax()))]:
+        xs = x[:, t, gi].numpy().astype(np.int64)
+        lo, hi = int(np.quantile(xs, 0.005)), int(np.quantile(xs, 0.995)) + 1
+        obs = np.bincount(np.clip(xs, lo, hi) - lo, minlength=hi - lo + 1).astype(np.float64)
+        dist = nbinom(n=float(c32[gi]), p=float(rate[t, gi] / (1 + rate[t, gi])))
+        exp = dist.pmf(np.arange(lo, hi + 1))
+        exp[0] = dist.cdf(lo)
+        exp[-1] = 1 - dist.cdf(hi - 1)
+        exp *= P
+        keep = exp > 5
+        chi2 = float((((obs - exp) ** 2) / np.maximum(exp, 1e-9))[keep].sum())
+        dof = int(keep.sum())
+        assert chi2 < dof + 6 * np.sqrt(2 * dof) + 10, (t, gi, chi2, dof)
+
+
 def test_sampler_perturbseq_accumulation_matches_torch():
     from cradle_vae_amd import ops
 
