@@ -412,6 +412,9 @@ int64_t cradle_elbo_step_intermediate(const cradle_step_desc* d, const char* nam
   if (!strcmp(name, "qc_E")) { *ptr = w.qcE; return PP * d->Q * d->L; }
   if (!strcmp(name, "z_offset")) { *ptr = w.zoff; return PN * 2 * d->L; }
   if (!strcmp(name, "logits")) { *ptr = w.logits; return PN * d->G; }
+  // diagnostics (tools/grad_errors.py): decoder layer-0 activation and pre-activation gradient, (P*N, Hd)
+  if (!strcmp(name, "dec_y0")) { *ptr = w.yd[0]; return PN * d->Hd; }
+  if (!strcmp(name, "dec_da0")) { *ptr = w.dad[0]; return PN * d->Hd; }
   return -1;
 }
 

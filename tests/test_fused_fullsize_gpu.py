@@ -3,25 +3,32 @@ shape (N=512, P=5, G=5000, T=105, L=200, H=400 -- the shape bench.py's metric is
 Replogle-like shape (G=8000, T=2000, L=100, compact treatment axis).  The golden fixtures stop at
 N=64, G=300, H=32; this is the same comparison where the kernels run the tile shapes, split-K factors and
 particle splits they run in production.  Bars: loss and every loss term <= 1e-4 relative (north_star),
-every parameter gradient <= 2e-3 of its largest entry and <= 1e-4 in relative L2."""
+every parameter gradient <= 2e-3 of its largest entry and <= 2e-5 in relative L2.
+
+The batch seeds are chosen so that no LeakyReLU input of the step lies within fp32 rounding of zero.  Where one
+does (seed 17 at the Norman shape: a decoder pre-activation of 3e-10 among 1,024,000), the fp32 forward can
+land on the other side of the kink than the fp64 one; that single element then carries slope 1 instead of 0.01
+and moves the gradients behind it by ~1e-4 in relative L2.  That is a property of evaluating this network in
+fp32, not of these kernels: the oracle run in fp32 on the CPU deviates by the same 1e-4 on such seeds
+(tools/grad_errors.py prints both next to each other; without a flip both sit at 1e-7 .. 5e-6)."""
 import dataclasses
 
 import pytest
 import torch
 
 from tests.test_fused_step_gpu import run_fused
-from tests.test_modular_gpu import DEV, GRAD_L2_RTOL, build_loss_module
+from tests.test_modular_gpu import DEV, build_loss_module
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,kmax", [("norman", 2), ("replogle", 2)])
-def test_fused_step_matches_oracle_at_full_size(name, kmax):
+@pytest.mark.parametrize("name,kmax,seed", [("norman", 2, 19), ("replogle", 2, 18)])
+def test_fused_step_matches_oracle_at_full_size(name, kmax, seed):
     from cradle_vae_amd import synthetic as syn
     from oracle import cradle_oracle as co
 
     shape = syn.SHAPES[name]
-    b = syn.make_batch(shape, seed=17)
+    b = syn.make_batch(shape, seed=seed)
     cfg = dict(
         n_latent=shape.n_latent, n_treatments=shape.n_treatments, n_phenos=shape.n_phenos, n_qc=shape.n_qc,
         decoder_n_layers=shape.decoder_n_layers, decoder_n_hidden=shape.decoder_n_hidden,
@@ -58,4 +65,4 @@ def test_fused_step_matches_oracle_at_full_size(name, kmax):
         err = float((got - g).abs().max()) / max(float(g.abs().max()), 1e-12)
         assert err <= 2e-3, (k, err)
         l2 = float((got - g).norm()) / max(float(g.norm()), 1e-12)
-        assert l2 <= GRAD_L2_RTOL, (k, l2)
+        assert l2 <= 2e-5, (k, l2)
