@@ -378,3 +378,60 @@ int64_t cradle_nb_workspace_floats(int P, int N, int G) {
 }
 
 }  // extern "C"
+
+// ---- the entry point that allocates nothing ------------------------------------------------------
+// cradle_nb_logprob_fwd_bwd needs scratch for the per-cell partial rows of d log_concentration
+// (N * particle_split * G floats) and takes it from the caller.  Callers that cannot allocate (code under
+// HIP graph capture, serving loops, harnesses that forbid hipMalloc) get the same computation with that
+// scratch in a file-scope device array of fixed size.  `scratch` is the host-side stand-in of the symbol,
+// not a device address: its address on each device is looked up once with hipGetSymbolAddress and only that
+// pointer is ever handed to a kernel.
+namespace {
+constexpr int64_t kStaticScratchFloats = 4ll << 20;  // 16 MiB per GPU: e.g. 512 cells x 8192 genes
+static __device__ __align__(256) float scratch[kStaticScratchFloats];
+float* g_scratch_ptr[16] = {};  // per device: each GPU holds its own copy of the array at its own address
+
+int static_scratch(float** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    cradle_set_error("nb_logprob_fwd_bwd_static: cannot identify the current device");
+    return CRADLE_ERR_HIP;
+  }
+  if (!g_scratch_ptr[dev]) {
+    float* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+      cradle_set_error("nb_logprob_fwd_bwd_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+      return CRADLE_ERR_HIP;
+    }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return CRADLE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t cradle_nb_static_scratch_floats(void) { return kStaticScratchFloats; }
+
+int cradle_nb_logprob_fwd_bwd_static(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
+                                     const float* X, int64_t ldx, const float* lib, const float* gene_consts,
+                                     const float* grow, float* out, float* dlog_c, int accumulate_dlog_c, int P, int N,
+                                     int G, hipStream_t stream) {
+  CRADLE_CHECK_ARG(P > 0 && N > 0 && G > 0, "nb_logprob_fwd_bwd_static: P=%d N=%d G=%d must be positive", P, N, G);
+  const int64_t need = cradle_nb_workspace_floats(P, N, G);
+  CRADLE_CHECK_ARG(need <= kStaticScratchFloats,
+                   "nb_logprob_fwd_bwd_static: N * particle_split * G = %lld floats of scratch exceed the built-in "
+                   "%lld (use cradle_nb_logprob_fwd_bwd with a caller workspace)",
+                   (long long)need, (long long)kStaticScratchFloats);
+  float* ws = nullptr;
+  const int rc = static_scratch(&ws);
+  if (rc) return rc;
+  // every partial row that the column sum reads is rewritten by the rows kernel of this call: nothing has
+  // to start at zero, whatever the previous call left behind
+  return cradle_nb_logprob_fwd_bwd(logits, ld_logits, dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, dlog_c,
+                                   accumulate_dlog_c, ws, kStaticScratchFloats, P, N, G, stream);
+}
+
+}  // extern "C"

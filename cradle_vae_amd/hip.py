@@ -40,6 +40,12 @@ PROTOTYPES = {
         [c_float_p, i64, c_float_p, i64, c_float_p, i64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, i32,
          c_float_p, i64, i32, i32, i32, ctypes.c_void_p, ctypes.c_void_p, c_stream],
     ),
+    "cradle_nb_logprob_fwd_bwd_static": (
+        i32,
+        [c_float_p, i64, c_float_p, i64, c_float_p, i64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, i32,
+         i32, i32, i32, c_stream],
+    ),
+    "cradle_nb_static_scratch_floats": (i64, []),
     "cradle_nb_workspace_floats": (i64, [i32, i32, i32]),
     "cradle_nb_particle_split": (i32, [i32, i32]),
     "cradle_nb_tune": (None, [i32, i32]),

@@ -90,6 +90,18 @@ int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, floa
                                     void* ev_begin, void* ev_end, cradle_stream_t stream);
 int64_t cradle_nb_workspace_floats(int P, int N, int G);
 int cradle_nb_particle_split(int P, int N);
+/* cradle_nb_logprob_fwd_bwd without the workspace argument, for callers that cannot allocate one: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * The per-cell partial rows live in a device array built into the library (cradle_nb_static_scratch_floats()
+ * floats = 16 MiB, held by every GPU the library runs on until the process ends); a problem that needs more
+ * (cradle_nb_workspace_floats(P, N, G) > that) is rejected with CRADLE_ERR_ARG.  Calls no hipMalloc/hipFree.
+ * All calls on one GPU share the array: calls that overlap on one GPU (two streams, two threads) race.
+ * Results are bit-identical to cradle_nb_logprob_fwd_bwd. */
+int cradle_nb_logprob_fwd_bwd_static(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
+                                     const float* X, int64_t ldx, const float* library, const float* gene_consts,
+                                     const float* grow, float* out, float* dlog_concentration, int accumulate,
+                                     int P, int N, int G, cradle_stream_t stream);
+int64_t cradle_nb_static_scratch_floats(void);
 /* tuning hook for tools/bench_nb.py: threads per workgroup (256/512/1024), particle split; -1 = auto */
 void cradle_nb_tune(int threads, int particle_split);
 
