@@ -4,6 +4,7 @@
 // backward needs.  Reference lines are cited per kernel (paths relative to /root/reference).
 #include "common.h"
 #include "kernels.h"
+#include "philox.h"
 
 namespace cradle {
 
@@ -15,6 +16,66 @@ __device__ __forceinline__ bool interior(float p) { return p > kEps32 && p < 1.0
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
 __device__ __forceinline__ bool finitef_(float x) { return fabsf(x) <= 3.4028234663852886e38f; }
+
+// =====================================================================================
+// The step's own noise: every random draw of one ELBO step in one launch.  The reference draws with torch's
+// generator inside the guide (uniforms for the relaxed-Bernoulli mask, correlated_normal_guide.py:139-141;
+// standard normals for E, qc_E, z_basal, :157,166,202-204); here a caller that passes no noise tensors gets
+// Philox4x32-10 draws keyed by two seeds -- one shared by all ranks for the perturbation-plated variables
+// (mask, E, qc_E must agree across data-parallel ranks), one per rank for the per-cell z_basal -- with the
+// step number in the counter.  Bit-parity with torch's generator is impossible either way; parity tests
+// inject the noise.  Tensor k of {u_mask, eps_E, eps_qc_E, eps_z} occupies float4 chunks [c0[k], c0[k+1]).
+// =====================================================================================
+struct NoisePlan {
+  float* dst[4];
+  int64_t n[4];        // elements
+  int64_t chunk0[5];   // first float4 chunk of each tensor, chunk0[4] = total
+};
+
+__global__ __launch_bounds__(256) void draw_noise_kernel(NoisePlan np, uint32_t plated_lo, uint32_t plated_hi,
+                                                         uint32_t local_lo, uint32_t local_hi, uint32_t step_lo,
+                                                         uint32_t step_hi) {
+  const int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ch >= np.chunk0[4]) return;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) k += ch >= np.chunk0[i] ? 1 : 0;
+  const int64_t local = ch - np.chunk0[k];
+  const Philox ph = k == 3 ? Philox{local_lo, local_hi} : Philox{plated_lo, plated_hi};
+  const uint4 r = ph((uint32_t)local, (uint32_t)(local >> 32) | ((uint32_t)k << 28), step_lo, step_hi);
+  float4 v;
+  if (k == 0) {  // uniforms in (0,1)
+    v = make_float4(u01(r.x), u01(r.y), u01(r.z), u01(r.w));
+  } else {  // Box-Muller, two pairs
+    const float r0 = sqrtf(-2.0f * logf(u01(r.x))), r1 = sqrtf(-2.0f * logf(u01(r.z)));
+    float s0, c0, s1, c1;
+    sincospif(2.0f * u01(r.y), &s0, &c0);
+    sincospif(2.0f * u01(r.w), &s1, &c1);
+    v = make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+  }
+  float* dst = np.dst[k] + local * 4;
+  const int64_t left = np.n[k] - local * 4;
+  if (left >= 4 && ((uintptr_t)dst & 15) == 0) {
+    *reinterpret_cast<float4*>(dst) = v;
+  } else {
+    const float vals[4] = {v.x, v.y, v.z, v.w};
+    for (int e = 0; e < 4 && e < left; ++e) dst[e] = vals[e];
+  }
+}
+
+int draw_noise(float* u_mask, float* eps_E, float* eps_qc_E, float* eps_z, int64_t n_mask, int64_t n_qc, int64_t n_z,
+               uint64_t seed_plated, uint64_t seed_local, uint64_t step, hipStream_t stream) {
+  NoisePlan np;
+  np.dst[0] = u_mask; np.dst[1] = eps_E; np.dst[2] = eps_qc_E; np.dst[3] = eps_z;
+  np.n[0] = n_mask; np.n[1] = n_mask; np.n[2] = n_qc; np.n[3] = n_z;
+  np.chunk0[0] = 0;
+  for (int k = 0; k < 4; ++k) np.chunk0[k + 1] = np.chunk0[k] + (np.n[k] + 3) / 4;
+  hipLaunchKernelGGL(draw_noise_kernel, dim3((unsigned)((np.chunk0[4] + 255) / 256)), dim3(256), 0, stream, np,
+                     (uint32_t)seed_plated, (uint32_t)(seed_plated >> 32), (uint32_t)seed_local,
+                     (uint32_t)(seed_local >> 32), (uint32_t)step, (uint32_t)(step >> 32));
+  CRADLE_CHECK_LAUNCH("draw_noise_kernel");
+  return CRADLE_OK;
+}
 
 // =====================================================================================
 // Dosage plan: dense D (N,T) -> ELL rows (gather) + CSC columns (scatter) + per-treatment counts.
@@ -154,14 +215,19 @@ __global__ __launch_bounds__(256) void csc_fill_kernel(const int* __restrict__ e
   }
 }
 
+// tcount <- 0, flags <- 0, tmap <- -1 in one launch (three memset nodes cost three boundaries on the plan's stream)
+__global__ __launch_bounds__(256) void plan_reset_kernel(int* __restrict__ tcount, int T, int* __restrict__ flags,
+                                                         int* __restrict__ tmap, int Tc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < T) tcount[i] = 0;
+  if (tmap && i < Tc) tmap[i] = -1;
+  if (i == 0) *flags = 0;
+}
+
 int build_dosage_plan(const float* D, int N, int T, const DosagePlan& plan, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(plan.tcount, 0, sizeof(int) * T, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(plan.flags, 0, sizeof(int), stream);
-  if (e == hipSuccess && plan.tmap) e = hipMemsetAsync(plan.tmap, 0xFF, sizeof(int) * plan.Tc, stream);  // -1
-  if (e != hipSuccess) {
-    cradle_set_error("build_dosage_plan: memset failed: %s", hipGetErrorString(e));
-    return CRADLE_ERR_HIP;
-  }
+  const int m = T > plan.Tc ? T : plan.Tc;
+  hipLaunchKernelGGL(plan_reset_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, plan.tcount, T, plan.flags, plan.tmap,
+                     plan.Tc);
   hipLaunchKernelGGL(dosage_rows_kernel, dim3(N), dim3(256), 0, stream, D, N, T, plan.kmax, plan.ell_idx, plan.ell_val,
                      plan.tcount, plan.flags);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, plan.tcount, T, plan.tstart, plan.Tc, plan.tmap,
@@ -799,16 +865,17 @@ __global__ __launch_bounds__(128) void enc_combine_bwd_kernel(const float* __res
 }
 
 // dvq[pp,q,:] = sum_n s_q[n] dpre[variant rows]; 16 columns x 64 cell slices per block
-__global__ __launch_bounds__(1024) void enc_combine_bwd_vq_kernel(const float* __restrict__ dpre, const float* __restrict__ qc,
-                                                                  float* __restrict__ dvq, int P, int N, int Q, int H) {
-  __shared__ float part[64][17];
+__global__ __launch_bounds__(256) void enc_combine_bwd_vq_kernel(const float* __restrict__ dpre, const float* __restrict__ qc,
+                                                                 float* __restrict__ dvq, int P, int N, int Q, int H) {
+  constexpr int SL = 16;  // row slices per workgroup
+  __shared__ float part[SL][17];
   const int q = blockIdx.y % Q, pp = blockIdx.y / Q;
   const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + c;
   const int64_t PN = (int64_t)P * N;
   float acc = 0.f;
   if (j < H) {
-    for (int n = sl; n < N; n += 64) {
+    for (int n = sl; n < N; n += SL) {
       const float s = qc[(int64_t)n * Q + q];
       if (pp < P) {
         const int64_t r = (int64_t)pp * N + n;
@@ -824,7 +891,7 @@ __global__ __launch_bounds__(1024) void enc_combine_bwd_vq_kernel(const float* _
   if (sl == 0 && j < H) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) t += part[k][c];
+    for (int k = 0; k < SL; ++k) t += part[k][c];
     dvq[((int64_t)pp * Q + q) * H + j] = t;
   }
 }
@@ -832,7 +899,7 @@ __global__ __launch_bounds__(1024) void enc_combine_bwd_vq_kernel(const float* _
 int enc_combine_bwd(const float* dpre, const float* qc, float* doffW, float* dxW, float* dvq, int P, int N, int Q, int H,
                     hipStream_t stream, hipStream_t vq_stream) {
   hipLaunchKernelGGL(enc_combine_bwd_kernel, dim3(N), dim3(128), 0, stream, dpre, doffW, dxW, P, N, H);
-  hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3((H + 15) / 16, 2 * P * Q), dim3(1024), 0, vq_stream, dpre, qc, dvq,
+  hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3((H + 15) / 16, 2 * P * Q), dim3(256), 0, vq_stream, dpre, qc, dvq,
                      P, N, Q, H);
   CRADLE_CHECK_LAUNCH("enc_combine_bwd");
   return CRADLE_OK;
@@ -913,56 +980,59 @@ int sum_over_groups_to_cols(const float* da, int groups, int T, int Tc, const in
 }
 
 // out[p, :] = sum_n w[n] da[p*N + n, :]   (gradient of the per-particle bad-variant shift)
-__global__ __launch_bounds__(1024) void weighted_rowgroup_sum_kernel(const float* __restrict__ da, const float* __restrict__ w,
-                                                                     int N, int H, float* __restrict__ out) {
-  // 16 columns x 64 row slices per block: 4x the blocks of a 64 x 16 arrangement for these short-wide sums
-  __shared__ float part[64][17];
+__global__ __launch_bounds__(256) void weighted_rowgroup_sum_kernel(const float* __restrict__ da, const float* __restrict__ w,
+                                                                    int N, int H, float* __restrict__ out) {
+  // 16 columns x 16 row slices per block (256 threads: runs on a side stream beside the backward GEMMs)
+  constexpr int SL = 16;
+  __shared__ float part[SL][17];
   const int p = blockIdx.y;
   const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + c;
   float acc = 0.f;
   if (j < H)
-    for (int n = sl; n < N; n += 64) acc = fmaf(w[n], da[((int64_t)p * N + n) * H + j], acc);
+    for (int n = sl; n < N; n += SL) acc = fmaf(w[n], da[((int64_t)p * N + n) * H + j], acc);
   part[sl][c] = acc;
   __syncthreads();
   if (sl == 0 && j < H) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) t += part[k][c];
+    for (int k = 0; k < SL; ++k) t += part[k][c];
     out[(int64_t)p * H + j] = t;
   }
 }
 
 int weighted_rowgroup_sum(const float* da, const float* w, int P, int N, int H, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(weighted_rowgroup_sum_kernel, dim3((H + 15) / 16, P), dim3(1024), 0, stream, da, w, N, H, out);
+  hipLaunchKernelGGL(weighted_rowgroup_sum_kernel, dim3((H + 15) / 16, P), dim3(256), 0, stream, da, w, N, H, out);
   CRADLE_CHECK_LAUNCH("weighted_rowgroup_sum_kernel");
   return CRADLE_OK;
 }
 
 // loss_modules.py:179-185: loss = -mean_{p,n}(sum of terms) + beta*KL; metrics = -mean of each term.
 // out: [0] loss, [1] reconstruction, [2] mask, [3] E, [4] qc_E, [5] z_basal, [6] cf_KLdivergence
-__global__ __launch_bounds__(1024) void finalize_loss_kernel(const float* __restrict__ recon, const float* __restrict__ wrec,
+// (256 threads: a single small workgroup finds a free slot beside the GEMMs it shares the chip with; a
+// 1024-thread one waited 170 us for a whole CU)
+__global__ __launch_bounds__(256) void finalize_loss_kernel(const float* __restrict__ recon, const float* __restrict__ wrec,
                                                              const float* __restrict__ ltz, const float* __restrict__ klrow,
                                                              const float* __restrict__ Smask, const float* __restrict__ SE,
                                                              const float* __restrict__ Sq, const float* __restrict__ cw,
                                                              const float* __restrict__ cwq, float beta, int P, int N, int T,
                                                              int Q, const int* __restrict__ flags, float* __restrict__ out) {
-  __shared__ float red[6][16];
+  __shared__ float red[6][4];
   float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int64_t PN = (int64_t)P * N;
-  for (int64_t r = threadIdx.x; r < PN; r += 1024) {
+  for (int64_t r = threadIdx.x; r < PN; r += 256) {
     a[0] += wrec[r % N] * recon[r];
     a[4] += ltz[r];
     a[5] += klrow[r];
   }
-  for (int r = threadIdx.x; r < P * T; r += 1024) {
+  for (int r = threadIdx.x; r < P * T; r += 256) {
     a[1] += cw[r % T] * Smask[r];
     a[2] += cw[r % T] * SE[r];
   }
-  for (int r = threadIdx.x; r < P * Q; r += 1024) a[3] += cwq[r % Q] * Sq[r];
+  for (int r = threadIdx.x; r < P * Q; r += 256) a[3] += cwq[r % Q] * Sq[r];
   float tot[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) tot[k] = block_sum<1024>(a[k], red[k]);
+  for (int k = 0; k < 6; ++k) tot[k] = block_sum<256>(a[k], red[k]);
   if (threadIdx.x == 0) {
     const float inv = 1.0f / (float)PN;
     float loss = 0.f;
@@ -982,7 +1052,7 @@ __global__ __launch_bounds__(1024) void finalize_loss_kernel(const float* __rest
 int finalize_loss(const float* recon, const float* wrec, const float* ltz, const float* klrow, const float* Smask,
                   const float* SE, const float* Sq, const float* cw, const float* cwq, float beta, int P, int N, int T,
                   int Q, const int* flags, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1024), 0, stream, recon, wrec, ltz, klrow, Smask, SE, Sq, cw, cwq,
+  hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(256), 0, stream, recon, wrec, ltz, klrow, Smask, SE, Sq, cw, cwq,
                      beta, P, N, T, Q, flags, out);
   CRADLE_CHECK_LAUNCH("finalize_loss_kernel");
   return CRADLE_OK;

@@ -27,6 +27,20 @@ using namespace cradle;
 // cradle_step_desc / cradle_mlp_ptrs: the one definition lives in the public header (via common.h)
 namespace {
 
+// Schedule experiments (tools only): CRADLE_SCHED is a bit mask read once.
+//   1: the decoder output layer's weight gradient is forked only after its data gradient (and that one's
+//      split-K reduction) has finished, so that the critical chain has the chip to itself for its largest kernel
+//   2: no side streams at all (everything on the caller's stream)
+// cradle_step_debug_stop_after(k): the step returns (all streams joined) right after its k-th checkpoint;
+// timing the truncated step in a steady-state loop gives the cumulative cost of its phases, boundaries and
+// cross-stream waits included, without a profiler (tools/phase_sweep.py).  0 = run everything.
+int g_stop_after = 0;
+
+int sched_flags() {
+  static const int v = getenv("CRADLE_SCHED") ? atoi(getenv("CRADLE_SCHED")) : 0;
+  return v;
+}
+
 struct Arena {
   char* base;
   int64_t off = 0;
@@ -61,6 +75,7 @@ struct Work {
   float *dheadsq, *Gq[2], *daq[CRADLE_MAX_LAYERS];
   float* splitk[3];  // one split-K scratch per stream
   int64_t nbws_floats;
+  float *u_mask, *eps_E, *eps_qc_E, *eps_z;  // the step's own draws (used when the caller passes none)
 };
 
 // Slots of the compact treatment axis (kernels.h, DosagePlan): a batch of N cells with at most kmax
@@ -168,6 +183,10 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   w.dmask_enc = a.take<float>(PT * L);
   w.dheadsq = a.take<float>((int64_t)Q * 2 * L);
   for (int i = 0; i < 3; ++i) w.splitk[i] = a.take<float>(kSplitKFloats);
+  w.u_mask = a.take<float>((int64_t)PP * T * L);
+  w.eps_E = a.take<float>((int64_t)PP * T * L);
+  w.eps_qc_E = a.take<float>((int64_t)PP * Q * L);
+  w.eps_z = a.take<float>(PN * L);
   return (a.off + 255) & ~int64_t(255);
 }
 
@@ -201,8 +220,10 @@ int get_streams(StreamSet** out) {
       cradle_set_error("elbo_step: marker stream creation failed");
       return CRADLE_ERR_HIP;
     }
+    unsigned evflags = hipEventDisableTiming;
+    if (getenv("CRADLE_EVFLAGS")) evflags |= (unsigned)strtoul(getenv("CRADLE_EVFLAGS"), nullptr, 0);
     for (int i = 0; i < kMaxEvents; ++i)
-      if (hipEventCreateWithFlags(&ss.ev[i], hipEventDisableTiming) != hipSuccess) {
+      if (hipEventCreateWithFlags(&ss.ev[i], evflags) != hipSuccess) {
         cradle_set_error("elbo_step: event creation failed");
         return CRADLE_ERR_HIP;
       }
@@ -314,7 +335,7 @@ void head_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, int Nout, const fl
 // as its da_k exists.  Pass wq == q to keep everything on one stream.
 const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, int M, int H, int Nout,
                             const float* dout, float* const* y, float* const* r, float* const* Gb, float* const* da,
-                            int q, int wq, int wq2, void* ev_head_done = nullptr) {
+                            int q, int wq, int wq2, void* ev_head_done = nullptr, bool delay_head_wgrad = false) {
   const int n = m.n_layers;
   int side = wq;
   auto wgrad = [&](GemmParams p) {
@@ -322,18 +343,21 @@ const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_p
     c.gemm(GEMM_TN, p, side);
     side = side == wq ? wq2 : wq;
   };
-  {  // dW_head = dout^T y_last, db_head = colsum(dout)
+  const bool head_wgrad_last = delay_head_wgrad;
+  auto head_wgrad = [&]() {  // dW_head = dout^T y_last, db_head = colsum(dout)
     GemmParams p = gp(dout, Nout, y[n - 1], H, g.W_head, H, Nout, H, M);
     p.extra_col = g.b_head;
     wgrad(p);
     mark_all(c, ev_head_done);  // the output layer's gradients have been enqueued
-  }
+  };
+  if (!head_wgrad_last) head_wgrad();
   int cur = 0;
   {  // G_{n-1} = dout W_head ; da_{n-1} = G_{n-1} * slope(r_{n-1})
     GemmParams p = gp(dout, Nout, m.W_head, H, Gb[cur], H, M, H, Nout);
     p.dact_src = n > 1 ? r[n - 1] : y[0]; p.ld_ds = H; p.C2 = da[n - 1]; p.ldc2 = H;
     c.gemm(GEMM_NN, p, q);
   }
+  if (head_wgrad_last) head_wgrad();
   for (int k = n - 1; k >= 1; --k) {
     {  // dW_k = da_k^T y_{k-1}
       GemmParams p = gp(da[k], H, y[k - 1], H, g.W[k], H, H, H, M);
@@ -379,7 +403,8 @@ int check_desc(const cradle_step_desc& d) {
   CRADLE_CHECK_ARG(!d.compute_grads || (d.d_q_mask_logits && d.d_log_concentration), "elbo_step: null gradient pointer");
   CRADLE_CHECK_ARG(d.X && d.cfX && d.D && d.qc && d.library_size && d.D_obs_counts && d.qc_obs_counts,
                    "elbo_step: null batch pointer");
-  CRADLE_CHECK_ARG(d.u_mask && d.eps_E && d.eps_qc_E && d.eps_z, "elbo_step: null noise pointer");
+  CRADLE_CHECK_ARG((d.u_mask && d.eps_E && d.eps_qc_E && d.eps_z) || (!d.u_mask && !d.eps_E && !d.eps_qc_E && !d.eps_z),
+                   "elbo_step: pass all four noise tensors or none (none: the step draws them itself)");
   CRADLE_CHECK_ARG(d.out && d.flags && d.workspace, "elbo_step: null output/workspace pointer");
   CRADLE_CHECK_ARG((uintptr_t)d.workspace % 256 == 0, "elbo_step: workspace must be 256-byte aligned");
   CRADLE_CHECK_ARG((uintptr_t)d.X % 16 == 0, "elbo_step: X must be 16-byte aligned");
@@ -412,6 +437,11 @@ int64_t cradle_elbo_step_intermediate(const cradle_step_desc* d, const char* nam
   if (!strcmp(name, "qc_E")) { *ptr = w.qcE; return PP * d->Q * d->L; }
   if (!strcmp(name, "z_offset")) { *ptr = w.zoff; return PN * 2 * d->L; }
   if (!strcmp(name, "logits")) { *ptr = w.logits; return PN * d->G; }
+  // the step's own draws (when the caller passed no noise)
+  if (!strcmp(name, "u_mask")) { *ptr = w.u_mask; return PP * d->T * d->L; }
+  if (!strcmp(name, "eps_E")) { *ptr = w.eps_E; return PP * d->T * d->L; }
+  if (!strcmp(name, "eps_qc_E")) { *ptr = w.eps_qc_E; return PP * d->Q * d->L; }
+  if (!strcmp(name, "eps_z")) { *ptr = w.eps_z; return PN * d->L; }
   // diagnostics (tools/grad_errors.py): decoder layer-0 activation and pre-activation gradient, (P*N, Hd)
   if (!strcmp(name, "dec_y0")) { *ptr = w.yd[0]; return PN * d->Hd; }
   if (!strcmp(name, "dec_da0")) { *ptr = w.dad[0]; return PN * d->Hd; }
@@ -431,6 +461,11 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   const float* Wenc0 = d.enc.W[0];
   const int64_t ldenc = (int64_t)G + 2 * L;
   const float* Wd0 = d.dec.W[0];
+  const bool own_noise = !d.u_mask;  // check_desc: all four given or none
+  const float* nz_u = own_noise ? w.u_mask : d.u_mask;
+  const float* nz_E = own_noise ? w.eps_E : d.eps_E;
+  const float* nz_q = own_noise ? w.eps_qc_E : d.eps_qc_E;
+  const float* nz_z = own_noise ? w.eps_z : d.eps_z;
 #define STEP(call)        \
   do {                    \
     rc = (call);          \
@@ -440,21 +475,26 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
 
   {
   // ================================================================== forward
-  // stream 1: log-standardise X and cfX, x Wx^T.   stream 2: q(qc_E) and the per-gene constants.
-  // stream 0 (caller's): dosage plan, q(M), q(E|M), gathers -- then joins both.
+  // stream 1: log-standardise X and cfX, x Wx^T (the longest side chain: it starts at once), then what only
+  //           the loss weights and the backward scatter need (CSC columns, per-cell weights).
+  // stream 2: dosage plan, per-gene constants, q(qc_E).
+  // stream 0 (caller's): the step's noise, q(M), q(E|M), gathers -- then joins both.
   c.after(1, 0);
   c.after(2, 0);
-  // the dosage plan and the per-cell weights depend on the batch only: first thing on stream 1.
-  // Full treatment axis: stream 0 starts with q(M) / q(E|M) straight away and meets the plan at
-  // the gather.  Compact axis: q(M) needs the slot map, so stream 0 waits for the plan's first part.
-  STEP(build_dosage_plan(d.D, N, T, w.plan, s1));
-  hipEvent_t ev_plan = c.record(1);
   STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s1));
   c.gemm(GEMM_NT, gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G), 1);  // x Wx^T, X and cfX
-  // what only the loss weights and the backward scatter need comes after the product the join waits for
+  // Full treatment axis: stream 0 starts with q(M) / q(E|M) straight away and meets the plan at
+  // the gather.  Compact axis: q(M) needs the slot map, so stream 0 waits for the plan's first part.
+  STEP(build_dosage_plan(d.D, N, T, w.plan, s2));
+  hipEvent_t ev_plan = c.record(2);
+  c.wait(1, ev_plan);
   STEP(build_dosage_plan_csc(N, T, w.plan, s1));
   STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, Tc, w.plan.tmap,
                  s1));
+  if (own_noise)
+    STEP(draw_noise(w.u_mask, w.eps_E, w.eps_qc_E, w.eps_z, (int64_t)PP * T * L, (int64_t)PP * Q * L, (int64_t)PN * L,
+                    d.rng_seed_plated, d.rng_seed_local, d.rng_step, s));
+  hipEvent_t ev_noise = own_noise ? c.record(0) : nullptr;  // stream 2's q(qc_E) draw reads eps_qc_E
 
   hipEvent_t ev_w0t = nullptr;
   if (!w.plan.tmap) {  // one-hot block of the embedding encoder's first layer as a (T, Hm) table: weights only
@@ -471,17 +511,19 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   trunk_fwd(c, d.qce, Q, Hm, w.yq, w.rq, 2);
   head_fwd(c, d.qce, Q, Hm, 2 * L, w.yq[d.qce.n_layers - 1], w.headsq, 2);
   if (c.rc) return c.rc;
-  STEP(qce_fwd(w.headsq, d.eps_qc_E, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.Sq, w.qsum, PP, P, Q, L, s2));
+  c.wait(2, ev_noise);
+  STEP(qce_fwd(w.headsq, nz_q, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.Sq, w.qsum, PP, P, Q, L, s2));
   c.gemm(GEMM_NT, gp(w.qcE, L, Wenc0 + G + L, ldenc, w.vq, He, PP * Q, He, L), 2);  // qc_E Wqc^T
   c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L), 2);        // bad-variant shift per particle
 
   if (w.plan.tmap) c.wait(0, ev_plan);
-  STEP(mask_fwd(d.q_mask_logits, d.u_mask, d.p_mask_probs, d.temperature, w.mask, w.soft, w.Smask, PP, T, Tc, w.plan.tmap,
+  STEP(mask_fwd(d.q_mask_logits, nz_u, d.p_mask_probs, d.temperature, w.mask, w.soft, w.Smask, PP, T, Tc, w.plan.tmap,
                 L, s));
   if (w.plan.tmap)
     STEP(gather_cols(d.emb.W[0], L + T, Hm, L, Tc, w.plan.tmap, w.W0tT, s));
   else
     c.wait(0, ev_w0t);
+  if (g_stop_after == 1) { c.after(0, 1); c.after(0, 2); return c.rc; }
   {  // layer 0: LeakyReLU(mask Wm^T + W_onehot[:, t] + b)
     GemmParams p = gp(w.mask, L, d.emb.W[0], L + T, w.yE[0], Hm, PT, Hm, L);
     p.bias = d.emb.b[0]; p.act = 1; p.rowbias = w.W0tT; p.ld_rb = Hm; p.rb_mode = 2; p.rb_n = Tc;
@@ -490,23 +532,26 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   trunk_fwd(c, d.emb, PT, Hm, w.yE, w.rE);
   head_fwd(c, d.emb, PT, Hm, 2 * L, w.yE[d.emb.n_layers - 1], w.headsE);
   if (c.rc) return c.rc;
+  if (g_stop_after == 2) { c.after(0, 1); c.after(0, 2); return c.rc; }
   // E, its scale and the log-ratio sums are needed by the loss and the backward pass only: stream 2 (idle by
   // now); the gather below draws the E it needs from the heads itself
   c.after(2, 0);
-  STEP(gaussE_fwd(w.headsE, d.eps_E, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.SE, PP, T, Tc, w.plan.tmap, L, s2));
+  STEP(gaussE_fwd(w.headsE, nz_E, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.SE, PP, T, Tc, w.plan.tmap, L, s2));
   if (!w.plan.tmap) c.wait(0, ev_plan);
-  STEP(gather_offsets(w.headsE, d.eps_E, w.mask, w.plan, w.zoff + L, 2 * L, w.offB, L, PP, P, N, T, L, s));  // D @ (mask*E)
+  STEP(gather_offsets(w.headsE, nz_E, w.mask, w.plan, w.zoff + L, 2 * L, w.offB, L, PP, P, N, T, L, s));  // D @ (mask*E)
   c.gemm(GEMM_NT, gp(w.offB, L, Wenc0 + G, ldenc, w.offW, He, 2 * PN, He, L));  // offsets . Woff^T, both passes
   c.after(0, 1);
   c.after(0, 2);
   if (c.rc) return c.rc;
+  if (g_stop_after == 3) return c.rc;
 
   // basal encoder (three variants), z_basal, counterfactual KL
   STEP(enc_combine_fwd(w.xW, w.offW, w.vq, d.enc.b[0], d.qc, w.yz[0], P, N, Q, He, s));
   trunk_fwd(c, d.enc, 3 * PN, He, w.yz, w.rz);
   head_fwd(c, d.enc, 3 * PN, He, 2 * L, w.yz[d.enc.n_layers - 1], w.headsz);
   if (c.rc) return c.rc;
-  STEP(zhead_fwd(w.headsz, d.eps_z, w.hascf, d.beta, w.zoff, 2 * L, w.sdz, w.ltz, w.klrow, w.dheadsz, P, N, L, s));
+  if (g_stop_after == 4) return c.rc;
+  STEP(zhead_fwd(w.headsz, nz_z, w.hascf, d.beta, w.zoff, 2 * L, w.sdz, w.ltz, w.klrow, w.dheadsz, P, N, L, s));
 
   // decoder, live variant per cell
   {
@@ -516,10 +561,12 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
     c.gemm(GEMM_NT, p);
   }
   trunk_fwd(c, d.dec, PN, Hd, w.yd, w.rd);
+  if (g_stop_after == 5) return c.rc;
   if (d.ev_gemm_begin) (void)hipEventRecord((hipEvent_t)d.ev_gemm_begin, s);
   head_fwd(c, d.dec, PN, Hd, G, w.yd[d.dec.n_layers - 1], w.logits);
   if (d.ev_gemm_end) (void)hipEventRecord((hipEvent_t)d.ev_gemm_end, s);
   if (c.rc) return c.rc;
+  if (g_stop_after == 6) return c.rc;
   }
   {
   if (!d.compute_grads) {
@@ -547,7 +594,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   // stream as soon as its inputs exist.  All streams are joined before returning.
   // decoder: logits now hold d loss / d logits
   const float* da0d = head_trunk_bwd(c, d.dec, d.d_dec, PN, Hd, G, w.logits, w.yd, w.rd, w.Gd, w.dad, 0, 1, 2,
-                                     d.ev_bucket[0]);  // (d log_c was enqueued on stream 2 above)
+                                     d.ev_bucket[0], (sched_flags() & 1) != 0);  // (d log_c was enqueued on stream 2 above)
   if (c.rc) return c.rc;
   c.after(2, 0);
   {  // dW0[:, :2L] = da0^T [z | off], db0
@@ -564,7 +611,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   if (c.rc) return c.rc;
 
   // basal encoder
-  STEP(zhead_bwd(w.headsz, d.eps_z, w.zoff, 2 * L, w.sdz, w.dzoff, 2 * L, w.dheadsz, P, N, L, s));
+  STEP(zhead_bwd(w.headsz, nz_z, w.zoff, 2 * L, w.sdz, w.dzoff, 2 * L, w.dheadsz, P, N, L, s));
   const float* dpre = head_trunk_bwd(c, d.enc, d.d_enc, 3 * PN, He, 2 * L, w.dheadsz, w.yz, w.rz, w.Gz, w.daz, 0, 1, 2);
   if (c.rc) return c.rc;
   c.after(2, 0);  // dvq on stream 2: it feeds dWqc and q(qc_E) only
@@ -585,7 +632,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   if (c.rc) return c.rc;
 
   // q(qc_E): whole backward on stream 2 (tiny, off the critical path; dq_dec and dq_enc were made there)
-  STEP(qce_bwd(w.headsq, d.eps_qc_E, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.dq_enc, w.dq_dec, w.cp.coefQ,
+  STEP(qce_bwd(w.headsq, nz_q, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.dq_enc, w.dq_dec, w.cp.coefQ,
                w.dheadsq, PP, P, Q, L, s2));
   const float* da0q = head_trunk_bwd(c, d.qce, d.d_qce, Q, Hm, 2 * L, w.dheadsq, w.yq, w.rq, w.Gq, w.daq, 2, 2, 2);
   {
@@ -596,7 +643,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   if (c.rc) return c.rc;
 
   // q(E|M), q(M)
-  STEP(gaussE_bwd(w.plan, w.dzoff + L, 2 * L, w.doffenc, L, w.doffenc + (int64_t)PN * L, L, w.headsE, d.eps_E, w.mask,
+  STEP(gaussE_bwd(w.plan, w.dzoff + L, 2 * L, w.doffenc, L, w.doffenc + (int64_t)PN * L, L, w.headsE, nz_E, w.mask,
                   d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.cp.coefTc, w.dheadsE, w.dmaskME, PP, P, N, T, L, s));
   const float* da0E = head_trunk_bwd(c, d.emb, d.d_emb, PT, Hm, 2 * L, w.dheadsE, w.yE, w.rE, w.GE, w.daE, 0, 1, 1);
   if (c.rc) return c.rc;
@@ -630,6 +677,7 @@ int prepare(const cradle_step_desc* dp, Work& w, Ctx& c, hipStream_t main) {
   rc = get_streams(&ss);
   if (rc) return rc;
   c.st[0] = main; c.st[1] = ss->side[0]; c.st[2] = ss->side[1];
+  if (sched_flags() & 2) c.st[1] = c.st[2] = main;
   c.marker = ss->marker;
   for (int i = 0; i < 3; ++i) c.splitk[i] = w.splitk[i];
   c.ev = ss->ev;
@@ -639,6 +687,8 @@ int prepare(const cradle_step_desc* dp, Work& w, Ctx& c, hipStream_t main) {
 }  // namespace
 
 extern "C" {
+
+void cradle_step_debug_stop_after(int checkpoint) { g_stop_after = checkpoint; }
 
 int cradle_elbo_step(const cradle_step_desc* dp, hipStream_t s) {
   Work w;

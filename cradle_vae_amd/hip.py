@@ -55,6 +55,7 @@ PROTOTYPES = {
     "cradle_gemm_f32_repeat": (i32, [ctypes.c_void_p, c_float_p, i64, i32, c_stream]),
     "cradle_elbo_step_workspace_bytes": (i64, [ctypes.c_void_p]),
     "cradle_elbo_step": (i32, [ctypes.c_void_p, c_stream]),
+    "cradle_step_debug_stop_after": (None, [i32]),
     "cradle_elbo_step_intermediate": (i64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
     "cradle_adam_step": (
         i32,
@@ -76,7 +77,7 @@ PROTOTYPES = {
 }
 
 MAX_LAYERS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MlpPtrs(ctypes.Structure):
@@ -107,7 +108,8 @@ class StepDesc(ctypes.Structure):
         + [("beta", ctypes.c_float), ("alpha", ctypes.c_float), ("compute_grads", i32)]
         + [("out", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
            ("workspace_bytes", i64), ("ev_k1_begin", ctypes.c_void_p), ("ev_k1_end", ctypes.c_void_p),
-           ("ev_gemm_begin", ctypes.c_void_p), ("ev_gemm_end", ctypes.c_void_p), ("ev_bucket", ctypes.c_void_p * 3)]
+           ("ev_gemm_begin", ctypes.c_void_p), ("ev_gemm_end", ctypes.c_void_p), ("ev_bucket", ctypes.c_void_p * 3),
+           ("rng_seed_plated", ctypes.c_uint64), ("rng_seed_local", ctypes.c_uint64), ("rng_step", ctypes.c_uint64)]
     )
 
 

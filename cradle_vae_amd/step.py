@@ -153,6 +153,12 @@ class FusedElboStep:
         # (trainer.TrainStep starts their all-reduce while the rest of the backward pass runs)
         self.bucket_events = None
         self._checked_states = set()
+        # Random draws of the step.  Default: the HIP step draws its own noise (Philox4x32-10 in one launch,
+        # csrc/elementwise.hip draw_noise_kernel) keyed by these seeds -- seed_plated identical on every
+        # data-parallel rank (mask, E, qc_E are shared latent variables), seed_local per rank (z_basal) -- and by
+        # rng_step, advanced every call.  Passing torch generators to run() draws with torch instead (four more
+        # launches on the step's critical path); passing noise tensors injects them (parity tests).
+        self.seed_plated, self.seed_local, self.rng_step = 0, 1, 0
 
     # ------------------------------------------------------------------ descriptor
     def _select_state(self, P, N):
@@ -216,9 +222,18 @@ class FusedElboStep:
             u_mask=torch.empty((2 * P, T, L), device=dev), eps_E=torch.empty((2 * P, T, L), device=dev),
             eps_qc_E=torch.empty((2 * P, Q, L), device=dev), eps_z=torch.empty((P, N, L), device=dev))
 
-    def _set_noise(self, noise, cf_noise, gen_plated=None, gen_local=None):
+    def _set_noise(self, noise, cf_noise, gen_plated=None, gen_local=None, rng_key=None):
         nz, d = self._noise, self.desc
         P = d.P
+        if noise is None and gen_plated is None and gen_local is None:
+            d.u_mask = d.eps_E = d.eps_qc_E = d.eps_z = None
+            if rng_key is not None:  # (seed_plated, seed_local, step) of this call, given by the caller
+                d.rng_seed_plated, d.rng_seed_local, d.rng_step = (int(v) & (2**64 - 1) for v in rng_key)
+                return
+            d.rng_seed_plated, d.rng_seed_local = self.seed_plated & (2**64 - 1), self.seed_local & (2**64 - 1)
+            d.rng_step = self.rng_step
+            self.rng_step += 1
+            return
         if noise is None:
             nz["u_mask"].uniform_(generator=gen_plated)
             nz["eps_E"].normal_(generator=gen_plated)
@@ -233,7 +248,7 @@ class FusedElboStep:
 
     # ------------------------------------------------------------------ launch
     def run(self, *, X, D, D_obs_counts, qc, qc_obs_counts, cfX, library_size, n_particles, noise=None, cf_noise=None,
-            compute_grads=True, gen_plated=None, gen_local=None):
+            compute_grads=True, gen_plated=None, gen_local=None, rng_key=None):
         """Launches the step; returns the (8,) device tensor [loss, 5 loss terms, cf KL, -]."""
         if not self.arena.valid():
             self.arena.rebuild()  # e.g. after module.to(device) or load_state_dict(assign=True)
@@ -247,7 +262,7 @@ class FusedElboStep:
         ins = (X, cfX, D, qc, library_size.reshape(-1), D_obs_counts, qc_obs_counts)
         self._keep = [t.contiguous().float() for t in ins]
         (d.X, d.cfX, d.D, d.qc, d.library_size, d.D_obs_counts, d.qc_obs_counts) = [hip.ptr(t) for t in self._keep]
-        self._set_noise(noise, cf_noise, gen_plated, gen_local)
+        self._set_noise(noise, cf_noise, gen_plated, gen_local, rng_key)
         d.beta = float(self.lm.beta)
         d.alpha = -1.0 if self.lm.alpha is None else float(self.lm.alpha)
         d.compute_grads = int(compute_grads)
@@ -310,9 +325,17 @@ class FusedElboStep:
                  cf_noise=None):
         """``loss_module.loss`` semantics: (loss with autograd node, metrics dict of device scalars)."""
         need_grads = torch.is_grad_enabled()
+        # Callers of loss() (Lightning's training_step) own the randomness through torch's global generator, as in
+        # the reference: the key of this call's device draws is taken from it (two host integers, no launch), so
+        # torch.manual_seed / seed_everything make a run reproducible and, as under Lightning DDP, ranks seeded
+        # alike draw alike.
+        key = None
+        if noise is None:
+            r = torch.randint(0, 2**62, (2,))
+            key = (int(r[0]), int(r[1]), 0)
         out = self.run(X=X, D=D, D_obs_counts=D_obs_counts, qc=qc, qc_obs_counts=qc_obs_counts, cfX=cfX,
                        library_size=library_size, n_particles=n_particles, noise=noise, cf_noise=cf_noise,
-                       compute_grads=need_grads)
+                       compute_grads=need_grads, rng_key=key)
         vals = out.clone()
         metrics = {k: vals[i] for i, k in enumerate(OUT_KEYS) if i > 0}
         if need_grads:

@@ -34,10 +34,13 @@ class TrainStep:
         self.lr, self.weight_decay = lr, weight_decay
         self.step_count = 0
         self.fused = None
+        # "device": the fused step draws its own noise (Philox, one launch); "torch": torch generators (4 launches)
+        self.rng = os.environ.get("CRADLE_STEP_RNG", "device")
         if loss_module._use_fused(None):
             from . import hip
 
             self.fused = loss_module._fused_step()
+            self.fused.seed_plated, self.fused.seed_local = seed, seed + 7919 * (rank + 1)
             self.impl = "fused"
             self.decoder_variants = 1
             a = self.fused.arena
@@ -66,7 +69,8 @@ class TrainStep:
         out = f.run(
             X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"],
             qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
-            n_particles=n_particles, gen_plated=self.gen_plated, gen_local=self.gen_local)
+            n_particles=n_particles, **({"gen_plated": self.gen_plated, "gen_local": self.gen_local}
+                                         if self.rng == "torch" else {}))
         a = f.arena
         if self.world_size > 1 and self.overlap:
             self._bucketed_allreduce(a)

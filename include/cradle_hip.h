@@ -186,6 +186,10 @@ typedef struct cradle_step_desc {
   const float* library_size;          /* (N) */
   const float* D_obs_counts;          /* (T) */
   const float* qc_obs_counts;         /* (Q) */
+  /* the random draws of the step: either all four given by the caller (parity tests inject the reference's),
+   * or all four NULL: the step then draws them itself into its workspace, Philox4x32-10 keyed by rng_seed_plated
+   * (mask, E, qc_E: must be the same on every data-parallel rank) and rng_seed_local (z_basal: per rank) with
+   * rng_step in the counter (the caller advances it every step) */
   const float* u_mask;    /* (2P, T, L) uniforms: particles [0,P) main guide pass, [P,2P) counterfactual pass */
   const float* eps_E;     /* (2P, T, L) standard normals */
   const float* eps_qc_E;  /* (2P, Q, L) */
@@ -211,15 +215,20 @@ typedef struct cradle_step_desc {
                              a third of all parameters, final first), [1] the other decoder gradients,
                              [2] basal-encoder gradients (d_enc.*); the rest is final with the step.
                              NULL = off */
+  uint64_t rng_seed_plated, rng_seed_local, rng_step;   /* used when the noise pointers are NULL */
 } cradle_step_desc;
 
 int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only the sizes are read */
 /* Inspection (parity tests): where an intermediate of the last step lives inside desc->workspace.
  * name: "mask", "E" (2P*Tc*L each, rows (particle, treatment slot): the guide's draws of
  * correlated_normal_guide.py:132-160), "qc_E" (2P*Q*L), "z_offset" (P*N rows [z_basal | D@(E*mask)], ld 2L:
- * the decoder input of model.py:121), "logits" (P*N*G).  Returns the element count, or -1. */
+ * the decoder input of model.py:121), "logits" (P*N*G), and the step's own draws "u_mask", "eps_E" (2P*T*L),
+ * "eps_qc_E" (2P*Q*L), "eps_z" (P*N*L).  Returns the element count, or -1. */
 int64_t cradle_elbo_step_intermediate(const cradle_step_desc* desc, const char* name, const float** ptr);
 int cradle_elbo_step(const cradle_step_desc* desc, cradle_stream_t stream);
+/* measuring hook for tools/phase_sweep.py (never used on the product path): the step returns after its k-th
+ * internal checkpoint with all streams joined (its outputs are then incomplete); 0 = run everything */
+void cradle_step_debug_stop_after(int checkpoint);
 /* ---- K10: gradient-norm clip + Adam over flat arenas -----------------------------------
  * Replaces Lightning's gradient_clip_val (train_norman.py:96; torch clip_grad_norm_) followed by
  * torch.optim.Adam(lr, weight_decay) (perturbation_lightning_module.py:147-150).

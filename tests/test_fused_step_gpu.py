@@ -165,6 +165,58 @@ def test_rejected_input_never_reaches_the_parameters():
                     condition_values={"library_size": bad["library_size"]}, n_particles=P)
 
 
+def test_step_draws_its_own_noise_when_given_none():
+    """No noise tensors, no torch generators: the step draws uniforms and standard normals itself (Philox keyed by
+    seed_plated / seed_local / step).  Same key -> same draws and the same loss; the plated draws depend on
+    seed_plated only (identical across data-parallel ranks), z_basal's on seed_local; moments as they should be."""
+    from cradle_vae_amd import synthetic as syn
+
+    case = gio.load_elbo("mid", torch.float32, DEV)
+    lm = build_loss_module(case)
+    fs = lm._fused_step()
+    b, P = case["batch"], case["cfg"]["n_particles"]
+    kw = dict(X=b["X"], D=b["D"], D_obs_counts=b["D_obs_counts"], qc=b["qc"], qc_obs_counts=b["qc_obs_counts"],
+              cfX=b["cfX"], library_size=b["library_size"], n_particles=P)
+
+    def draw(seed_plated, seed_local, step):
+        fs.seed_plated, fs.seed_local, fs.rng_step = seed_plated, seed_local, step
+        out = fs.run(**kw).clone()
+        return out, {k: fs.intermediate(k) for k in ("u_mask", "eps_E", "eps_qc_E", "eps_z")}
+
+    o1, n1 = draw(5, 6, 0)
+    o2, n2 = draw(5, 6, 0)
+    assert torch.equal(o1, o2) and all(torch.equal(n1[k], n2[k]) for k in n1) and torch.isfinite(o1[0])
+    assert fs.rng_step == 1  # advanced by the call
+    o3, n3 = draw(5, 6, 1)
+    assert not torch.equal(n1["eps_z"], n3["eps_z"]) and not torch.equal(n1["u_mask"], n3["u_mask"]) and float(o3[0]) != float(o1[0])
+    _, n4 = draw(5, 77, 0)  # another rank: same plated draws, its own z_basal noise
+    assert all(torch.equal(n1[k], n4[k]) for k in ("u_mask", "eps_E", "eps_qc_E")) and not torch.equal(n1["eps_z"], n4["eps_z"])
+    _, n5 = draw(9, 6, 0)
+    assert not torch.equal(n1["eps_E"], n5["eps_E"]) and torch.equal(n1["eps_z"], n5["eps_z"])
+    # moments at a size where they mean something
+    shape = syn.NORMAN
+    fs2 = None
+    import bench
+    lm2, batch = bench.build(shape, DEV, seed=3)
+    fs2 = lm2._fused_step()
+    fs2.seed_plated, fs2.seed_local = 11, 12
+    fs2.run(X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"],
+            qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
+            n_particles=shape.n_particles, compute_grads=False)
+    u = fs2.intermediate("u_mask").double()
+    assert 0.0 < float(u.min()) and float(u.max()) < 1.0
+    n = u.numel()
+    assert abs(float(u.mean()) - 0.5) < 5 * (1 / 12 / n) ** 0.5 and abs(float(u.var()) - 1 / 12) < 5e-3
+    for k in ("eps_E", "eps_z"):
+        e = fs2.intermediate(k).double()
+        m = e.numel()
+        assert abs(float(e.mean())) < 5 / m ** 0.5, (k, float(e.mean()))
+        assert abs(float(e.var()) - 1.0) < 5 * (2 / m) ** 0.5, (k, float(e.var()))
+        assert abs(float((e ** 4).mean()) - 3.0) < 0.1 and float(e.abs().max()) < 7.0  # kurtosis, tails
+        lag = float((e[:-1] * e[1:]).mean())
+        assert abs(lag) < 5 / m ** 0.5, (k, lag)  # neighbours (the two halves of a Box-Muller pair) uncorrelated
+
+
 @pytest.mark.parametrize("name", gio.elbo_cases())
 def test_fused_step_draws_match_reference(name):
     """The hot path's own intermediates against the reference guide's draws (same injected noise):

@@ -13,8 +13,7 @@ lm, batch = bench.build(shape, "cuda:0", seed=1000)
 st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0)
 f = st.fused
 kw = dict(X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"], qc_obs_counts=batch["qc_obs_counts"],
-          cfX=batch["cfX"], library_size=batch["library_size"], n_particles=shape.n_particles,
-          gen_plated=st.gen_plated, gen_local=st.gen_local)
+          cfX=batch["cfX"], library_size=batch["library_size"], n_particles=shape.n_particles)
 
 
 def timeit(fn, n=steps):

@@ -1,0 +1,7 @@
+#!/bin/bash
+# bench.py under each CRADLE_SCHED value given as arguments (schedule experiments of csrc/step.hip)
+set -o pipefail
+for s in "$@"; do
+  echo "== CRADLE_SCHED=$s"
+  CRADLE_SCHED=$s timeout -k 10 200 python bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-secondary | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms/step %.4f  cells/s %.0f  k1 %.1f us  gemm %.1f us' % (d['ms_per_step'], d['value'], d['roofline']['launch_us'], d['mfma']['largest_gemm']['launch_us']))" || exit 1
+done
