@@ -17,32 +17,17 @@ from typing import Dict, List, Literal, Optional, Sequence
 import numpy as np
 import torch
 
+from . import functional as F_hip
 from . import ops, parallel
 
-MAX_ROWS_PER_LAUNCH = 1 << 16  # decoder rows (particles x conditions) per GEMM chain / sampler launch
+MAX_ROWS_PER_LAUNCH = 1 << 16  # decoder rows (particles x conditions) per GEMM chain / sampler launch ...
+MAX_LOGIT_FLOATS = 1 << 27     # ... and at most 512 MB of decoder logits at a time
 
 
 def _chunk_generator(device, seed: int, chunk_idx: int) -> torch.Generator:
     g = torch.Generator(device=device)
     g.manual_seed((seed * 1000003 + chunk_idx) & (2**63 - 1))
     return g
-
-
-def _latent_offsets(D: torch.Tensor, EM: torch.Tensor) -> torch.Tensor:
-    """D (C, T) @ EM (c, T, L) -> (c, C, L) through the non-zero pattern of D (<= a few guides
-    per perturbation: model.py:115 with one-hot / few-hot dosages)."""
-    nnz = int((D != 0).sum(dim=1).max().item()) if D.numel() else 0
-    if nnz == 0:
-        return torch.zeros((EM.shape[0], D.shape[0], EM.shape[2]), device=EM.device, dtype=EM.dtype)
-    if nnz > 8:
-        return torch.matmul(D, EM)
-    w, idx = torch.topk(D.abs(), nnz, dim=1)  # (C, nnz): positions of the non-zeros (ties at 0 carry weight 0)
-    w = torch.gather(D, 1, idx)
-    out = None
-    for k in range(nnz):
-        term = EM[:, idx[:, k], :] * w[:, k].reshape(1, -1, 1)
-        out = term if out is None else out + term
-    return out
 
 
 @torch.no_grad()
@@ -85,6 +70,10 @@ def estimate_model_average_treatment_effect(
         raise ValueError("the ATE estimator takes one library size shared by all conditions (eval.py:95)")
     D_all = torch.cat([D_ctl, D_alt], dim=0)
     C, L, G = D_all.shape[0], model.n_latent, model.n_phenos
+    # the conditions' dosages as lists of their non-zeros, built once: every D @ (E * mask) below is a gather of
+    # <= kmax rows per condition (the reference runs one dense model call per perturbation, :178-195)
+    kmax = max(1, int((D_all != 0).sum(dim=1).max().item()))
+    plan = F_hip.DosagePlan(D_all, kmax) if kmax <= 64 else None
     share_z = dosage_independent_variables is not None and "z_basal" in dosage_independent_variables
     gene_consts = ops.nb_gene_consts(model.decoder.log_concentration.detach())
     sums = torch.zeros((C, G), device=device, dtype=torch.float32)
@@ -95,20 +84,17 @@ def estimate_model_average_treatment_effect(
         i = starts[ci]
         c = min(batch_size, n_particles - i)
         gen = _chunk_generator(device, seed, ci)
+        nz = {}
         if noise_chunks is not None:
             nz = {k: v.to(device=device, dtype=torch.float32) for k, v in noise_chunks[ci].items()}
-        else:
-            T, Q = guide.n_treatments, guide.n_qc
-            nz = dict(
-                u_mask=torch.rand((c, T, L), device=device, generator=gen),
-                eps_E=torch.randn((c, T, L), device=device, generator=gen),
-                eps_qc_E=torch.randn((c, Q, L), device=device, generator=gen),
-            )
         plated_cv = {k: v for k, v in cv.items() if k in ("mask", "E", "qc_E")}
-        _, gs = guide(n_particles=c, condition_values=plated_cv, noise=nz)  # :143-145
-        EM = gs["E"] * gs["mask"]
+        # :143-145; draws that are not injected come from this chunk's generator inside the guide (in slabs of
+        # treatments when there are thousands: no (c, T, L) noise tensors up front)
+        _, gs = guide(n_particles=c, condition_values=plated_cv, noise=nz, generator=gen)
+        EM = gs["E"] * gs["mask"] if "E" in plated_cv else gs["E"].mul_(gs["mask"])  # in place: E is this call's own
+        del gs
         # conditions in slabs so that one decoder pass stays within MAX_ROWS_PER_LAUNCH rows
-        slab = max(1, MAX_ROWS_PER_LAUNCH // c)
+        slab = max(1, min(MAX_ROWS_PER_LAUNCH, MAX_LOGIT_FLOATS // G) // c)
         z_shared = None
         for s0 in range(0, C, slab):
             s1 = min(C, s0 + slab)
@@ -127,7 +113,7 @@ def estimate_model_average_treatment_effect(
                 z = z_shared.expand(c, n, L)
             else:  # p_z_basal = Normal(0, 1) drawn per call (model.py:82)
                 z = torch.randn((c, n, L), device=device, generator=gen)
-            off = _latent_offsets(D_all[s0:s1], EM)
+            off = F_hip.dosage_matmul(plan.rows(s0, s1), EM, c) if plan is not None else torch.matmul(D_all[s0:s1], EM)
             z_good = torch.cat([z, off, torch.zeros((c, n, L), device=device)], dim=-1)  # model.py:121
             p_x_good = model.decoder(z_good, lib)
             call_seed = (seed * 7919 + ci) * 4099 + s0

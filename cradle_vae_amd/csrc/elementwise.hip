@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void dosage_rows_kernel(const float* __restric
     if (pos < kmax) {
       idx[pos] = t;
       val[pos] = v;
-      atomicAdd(&tcount[t], 1);
+      if (tcount) atomicAdd(&tcount[t], 1);
     }
   };
   if ((T & 3) == 0 && ((uintptr_t)D & 15) == 0) {
@@ -242,6 +242,118 @@ int build_dosage_plan_csc(int N, int T, const DosagePlan& plan, hipStream_t stre
   CRADLE_CHECK_LAUNCH("csc_fill_kernel");
   return CRADLE_OK;
 }
+
+// =====================================================================================
+// K4 as stand-alone operators (C ABI: cradle_dosage_rows / cradle_gather_sum / cradle_scatter_sum): every
+// matmul(D, .) / matmul(qc, .) of the module-level API -- guide.forward (correlated_normal_guide.py:186-194),
+// model.forward (model.py:118-122), the plated re-weighting (loss_modules.py:224-232), the ATE estimator's
+// per-perturbation offsets (average_treatment_effects.py:157-162,183-188) -- through the <= kmax non-zeros of
+// each row instead of a dense (N,T) x (P,T,L) product.  A dense matmul also propagates NaN/Inf from rows
+// that no cell selects; the gather does not (vii).
+// =====================================================================================
+// out[p, n, :] = sum_k val[n, k] * table[p, idx[n, k], :]
+template <bool VEC>
+__global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict__ table, int64_t sp, int64_t st,
+                                                         const int* __restrict__ ell_idx, const float* __restrict__ ell_val,
+                                                         int kmax, float* __restrict__ out, int64_t op, int64_t on, int L) {
+  const int n = blockIdx.x, p = blockIdx.y;
+  const float* tb = table + (int64_t)p * sp;
+  float* o = out + (int64_t)p * op + (int64_t)n * on;
+  const int* ix = ell_idx + (int64_t)n * kmax;
+  const float* vl = ell_val + (int64_t)n * kmax;
+  if (VEC) {
+    for (int l4 = threadIdx.x; l4 < L / 4; l4 += blockDim.x) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < kmax; ++k) {
+        const int t = ix[k];
+        if (t < 0) break;
+        const float v = vl[k];
+        const float4 r = reinterpret_cast<const float4*>(tb + (int64_t)t * st)[l4];
+        acc.x = fmaf(v, r.x, acc.x); acc.y = fmaf(v, r.y, acc.y); acc.z = fmaf(v, r.z, acc.z); acc.w = fmaf(v, r.w, acc.w);
+      }
+      reinterpret_cast<float4*>(o)[l4] = acc;
+    }
+  } else {
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+      float acc = 0.f;
+      for (int k = 0; k < kmax; ++k) {
+        const int t = ix[k];
+        if (t < 0) break;
+        acc = fmaf(vl[k], tb[(int64_t)t * st + l], acc);
+      }
+      o[l] = acc;
+    }
+  }
+}
+
+// The transpose (backward of the gather): dtable[p, t, :] = sum over entries (n, k) with idx[n, k] == t of
+// val[n, k] * dout[p, n, :].  One workgroup per (t, p) scans the N*kmax entries in order: deterministic, no
+// atomics; the entry list is tiny (a batch of cells) next to the table.
+__global__ __launch_bounds__(256) void scatter_sum_kernel(const float* __restrict__ dout, int64_t op, int64_t on,
+                                                          const int* __restrict__ ell_idx, const float* __restrict__ ell_val,
+                                                          int entries, int kmax, float* __restrict__ dtable, int64_t sp,
+                                                          int64_t st, int L) {
+  const int t = blockIdx.x, p = blockIdx.y;
+  float* dst = dtable + (int64_t)p * sp + (int64_t)t * st;
+  const float* src = dout + (int64_t)p * op;
+  for (int l = threadIdx.x; l < L; l += blockDim.x) {
+    float acc = 0.f;
+    for (int e = 0; e < entries; ++e)
+      if (ell_idx[e] == t) acc = fmaf(ell_val[e], src[(int64_t)(e / kmax) * on + l], acc);
+    dst[l] = acc;
+  }
+}
+
+}  // namespace cradle
+
+extern "C" {
+
+int cradle_dosage_rows(const float* D, int N, int T, int kmax, int* ell_idx, float* ell_val, int* flags,
+                       hipStream_t stream) {
+  CRADLE_CHECK_ARG(D && ell_idx && ell_val && flags && N > 0 && T > 0, "dosage_rows: bad arguments");
+  CRADLE_CHECK_ARG(kmax >= 1 && kmax <= cradle::kMaxDosages, "dosage_rows: kmax=%d out of range [1,%d]", kmax,
+                   cradle::kMaxDosages);
+  hipLaunchKernelGGL(cradle::dosage_rows_kernel, dim3(N), dim3(256), 0, stream, D, N, T, kmax, ell_idx, ell_val,
+                     (int*)nullptr, flags);
+  CRADLE_CHECK_LAUNCH("dosage_rows_kernel");
+  return CRADLE_OK;
+}
+
+int cradle_gather_sum(const float* table, int64_t stride_p, int64_t stride_t, const int* ell_idx, const float* ell_val,
+                      int P, int N, int kmax, int L, float* out, int64_t out_stride_p, int64_t out_stride_n,
+                      hipStream_t stream) {
+  CRADLE_CHECK_ARG(table && ell_idx && ell_val && out && P > 0 && N > 0 && kmax > 0 && L > 0, "gather_sum: bad arguments");
+  CRADLE_CHECK_ARG(P <= 65535, "gather_sum: at most 65535 particles per call");
+  const bool vec = L % 4 == 0 && stride_p % 4 == 0 && stride_t % 4 == 0 && out_stride_p % 4 == 0 && out_stride_n % 4 == 0 &&
+                   (uintptr_t)table % 16 == 0 && (uintptr_t)out % 16 == 0;
+  const int work = vec ? L / 4 : L;
+  const int nt = work <= 64 ? 64 : (work <= 128 ? 128 : 256);
+  if (vec)
+    hipLaunchKernelGGL(cradle::gather_sum_kernel<true>, dim3(N, P), dim3(nt), 0, stream, table, stride_p, stride_t, ell_idx,
+                       ell_val, kmax, out, out_stride_p, out_stride_n, L);
+  else
+    hipLaunchKernelGGL(cradle::gather_sum_kernel<false>, dim3(N, P), dim3(nt), 0, stream, table, stride_p, stride_t, ell_idx,
+                       ell_val, kmax, out, out_stride_p, out_stride_n, L);
+  CRADLE_CHECK_LAUNCH("gather_sum_kernel");
+  return CRADLE_OK;
+}
+
+int cradle_scatter_sum(const float* dout, int64_t out_stride_p, int64_t out_stride_n, const int* ell_idx,
+                       const float* ell_val, int P, int N, int kmax, int T, int L, float* dtable, int64_t stride_p,
+                       int64_t stride_t, hipStream_t stream) {
+  CRADLE_CHECK_ARG(dout && ell_idx && ell_val && dtable && P > 0 && N > 0 && kmax > 0 && T > 0 && L > 0,
+                   "scatter_sum: bad arguments");
+  CRADLE_CHECK_ARG(P <= 65535, "scatter_sum: at most 65535 particles per call");
+  const int nt = L <= 64 ? 64 : (L <= 128 ? 128 : 256);
+  hipLaunchKernelGGL(cradle::scatter_sum_kernel, dim3(T, P), dim3(nt), 0, stream, dout, out_stride_p, out_stride_n, ell_idx,
+                     ell_val, N * kmax, kmax, dtable, stride_p, stride_t, L);
+  CRADLE_CHECK_LAUNCH("scatter_sum_kernel");
+  return CRADLE_OK;
+}
+
+}  // extern "C"
+
+namespace cradle {
 
 // =====================================================================================
 // Per-cell weights of loss_modules.py:137-143 and the plate reweighting of :200-232.

@@ -76,3 +76,92 @@ class _NBLogProb(torch.autograd.Function):
 def nb_logprob(logits: torch.Tensor, X: torch.Tensor, lib: torch.Tensor, log_c: torch.Tensor, P: int) -> torch.Tensor:
     """logits (P*N, G) -> (P*N,) summed log-likelihood (loss_modules.py:134-135,143)."""
     return _NBLogProb.apply(logits.contiguous(), X.contiguous(), lib.contiguous(), log_c.contiguous(), P)
+
+
+# ---------------------------------------------------------------------------------------------
+# K4: matmul(D, table) through the non-zeros of D
+# ---------------------------------------------------------------------------------------------
+class DosagePlan:
+    """ELL form of a dense (N, T) dosage / indicator matrix (<= ``kmax`` non-zeros per row).  ``overflow`` is a
+    device flag (non-zero: some row has more, the gathers below are then wrong and the caller must redo the product
+    densely -- ``check()`` raises, costing one sync)."""
+
+    def __init__(self, D: torch.Tensor, kmax: int = 8, flags: Optional[torch.Tensor] = None):
+        self.N, self.T = D.shape
+        self.idx, self.val, self.overflow = ops.dosage_rows(D, kmax, flags)
+        self.kmax = self.idx.shape[1]
+
+    def rows(self, s0: int, s1: int) -> "DosagePlan":
+        out = object.__new__(DosagePlan)
+        out.N, out.T, out.kmax, out.overflow = s1 - s0, self.T, self.kmax, self.overflow
+        out.idx, out.val = self.idx[s0:s1].contiguous(), self.val[s0:s1].contiguous()
+        return out
+
+    def check(self):
+        if int(self.overflow.item()) & 1:
+            raise RuntimeError(f"a row of the dosage matrix has more than kmax={self.kmax} non-zeros")
+
+
+class _DosageMatmul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, plan, P):
+        ctx.plan, ctx.shape = plan, table.shape
+        return ops.gather_sum(table, plan.idx, plan.val, P)
+
+    @staticmethod
+    def backward(ctx, dout):
+        plan = ctx.plan
+        d = ops.scatter_sum(dout, plan.idx, plan.val, plan.T)  # (P, T, L)
+        if len(ctx.shape) == 2:
+            d = d.sum(0)
+        elif ctx.shape[0] == 1 and d.shape[0] != 1:
+            d = d.sum(0, keepdim=True)
+        return d, None, None
+
+
+def dosage_matmul(plan: DosagePlan, table: torch.Tensor, n_particles: Optional[int] = None) -> torch.Tensor:
+    """``torch.matmul(D, table)`` for D (N, T) given as its ``DosagePlan`` and table (P, T, L) or (T, L)
+    -> (P, N, L) (or (N, L) for a 2-D table without ``n_particles``)."""
+    squeeze = table.dim() == 2 and n_particles is None
+    P = n_particles if n_particles is not None else (table.shape[0] if table.dim() == 3 else 1)
+    if not table.is_contiguous():
+        table = table.contiguous()
+    out = _DosageMatmul.apply(table, plan, P)
+    return out[0] if squeeze else out
+
+
+class _OneHotLinear(torch.autograd.Function):
+    """First layer of the embedding encoder on the input [mask | one_hot(t)] (correlated_normal_guide.py:
+    147-153) without the one-hot: y[p, j, :] = LeakyReLU(mask[p, j] W[:, :L]^T + W[:, L + t_j] + b), the one-hot
+    block entering as a per-row bias of the GEMM epilogue.  ``t0``: the rows are treatments t0 .. t0 + Ts - 1."""
+
+    @staticmethod
+    def forward(ctx, mask, W, b, t0):
+        Pn, Ts, L = mask.shape
+        x2 = mask.reshape(Pn * Ts, L)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        table = W[:, L + t0:L + t0 + Ts].t().contiguous()  # (Ts, H): weights only
+        y = ops.gemm(ops.NT, x2, W[:, :L], bias=b, act=True, rowbias=table, rowbias_mode=2, rowbias_n=Ts)
+        ctx.save_for_backward(x2, W, y)
+        ctx.dims = (Pn, Ts, L, t0)
+        return y.reshape(Pn, Ts, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        Pn, Ts, L, t0 = ctx.dims
+        H = W.shape[0]
+        da = dy.reshape(Pn * Ts, H) * torch.where(y > 0, 1.0, LEAKY_SLOPE)
+        dmask = ops.gemm(ops.NN, da, W[:, :L]).reshape(Pn, Ts, L) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1]:
+            dW = torch.zeros_like(W)
+            db = torch.empty((H,), device=W.device, dtype=torch.float32)
+            ops.gemm(ops.TN, da, x2, out=dW[:, :L], extra_col=db)
+            dW[:, L + t0:L + t0 + Ts] = da.reshape(Pn, Ts, H).sum(0).t()
+        return dmask, dW, db, None
+
+
+def onehot_linear(mask: torch.Tensor, W: torch.Tensor, b: torch.Tensor, t0: int = 0) -> torch.Tensor:
+    return _OneHotLinear.apply(mask, W, b, t0)

@@ -9,8 +9,15 @@ from typing import Dict, Literal, Optional, Tuple
 import torch
 from torch import nn
 
+from . import functional as F_hip
 from .distributions import GumbelSoftmaxBernoulliStraightThrough
 from .mlp import get_likelihood_mlp
+
+# (particle, treatment) rows of the embedding encoder evaluated at once when no gradient is needed: with
+# thousands of treatments and a hundred particles the rows run into the millions (2 GB per activation at
+# H = 400), so the plated variables are then evaluated in slabs of treatments (rows are independent)
+MAX_PLATED_ROWS = 1 << 17
+MAX_ONE_HOT_BUFFER = 4096
 
 
 @dataclass
@@ -68,9 +75,11 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
         self.param_dict["q_mask_logits"] = nn.Parameter(mask_init_logits * torch.ones((n_treatments, n_latent)))
         self.embedding_encoder = get_likelihood_mlp(
             "normal", n_latent + n_treatments, n_latent, embedding_encoder_n_layers, embedding_encoder_n_hidden)
-        # kept for state-dict compatibility (correlated_normal_guide.py:64); the HIP path never
-        # multiplies by it: the one-hot block of the first layer is a column gather
-        self.register_buffer("treatment_one_hot", torch.eye(n_treatments))
+        # kept for state-dict compatibility (correlated_normal_guide.py:64) while it is small; the HIP path never
+        # multiplies by it (the one-hot block of the first layer is a column lookup), and at 10 k treatments it
+        # would be 400 MB of identity matrix: beyond MAX_ONE_HOT_BUFFER treatments the key is dropped on load
+        if n_treatments <= MAX_ONE_HOT_BUFFER:
+            self.register_buffer("treatment_one_hot", torch.eye(n_treatments))
         self.normalization_module = LogStandardizationModule(x_normalization_stats)
         self.register_buffer("qc_encoder_input", torch.ones((n_qc, n_latent)))
         self.qc_encoder = get_likelihood_mlp(
@@ -79,9 +88,19 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
             "normal", n_phenos + 2 * n_latent, n_latent, basal_encoder_n_layers, basal_encoder_n_hidden)
         self.register_buffer("gs_temperature", gs_temperature * torch.ones((1,)))
         self.var_eps = 1e-4
+        # matmul(D, .) runs through the non-zero dosages of each cell (<= this many; a row with more raises the
+        # `dosage_overflow` flag that the callers check once per call and answer with dense_dosage_matmul = True)
+        self.max_dosages_per_cell = 8
+        self.dense_dosage_matmul = False
+        self.dosage_overflow = None
 
     def get_var_keys(self):
         return ["z_basal", "E", "mask", "qc_E"]
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        if self.n_treatments > MAX_ONE_HOT_BUFFER:  # a reference checkpoint carries eye(T): not needed here
+            state_dict.pop(prefix + "treatment_one_hot", None)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     @staticmethod
     def sanitize_tensor(tensor):
@@ -97,10 +116,12 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
         n_particles: int = 1,
         noise: Optional[Dict[str, torch.Tensor]] = None,
         need_cf_basal: bool = True,
+        generator: Optional[torch.Generator] = None,
     ) -> Tuple[Dict[str, object], Dict[str, torch.Tensor]]:
         """correlated_normal_guide.py:102-209.  ``noise`` (keys u_mask, eps_E, eps_qc_E, eps_z)
         injects the random draws; missing keys are drawn with torch's generator.
-        ``need_cf_basal=False`` (inference only) skips ``q_z_cf_basal``, which the predictor never reads."""
+        ``need_cf_basal=False`` (inference only) skips ``q_z_cf_basal``, which the predictor never reads.
+        ``generator`` draws whatever ``noise`` does not supply (default: torch's global generator)."""
         cv = {} if condition_values is None else condition_values
         noise = {} if noise is None else noise
         P = n_particles
@@ -110,28 +131,53 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
         def rsample(dist, key):
             eps = noise.get(key)
             if eps is None:
-                return dist.rsample()
+                eps = torch.randn(dist.mean.shape, device=dist.mean.device, dtype=dist.mean.dtype, generator=generator)
             return dist.mean + dist.stddev * eps
+
+        def uniforms(t0, t1):
+            if "u_mask" in noise:
+                return noise["u_mask"][:, t0:t1]
+            return torch.rand((P, t1 - t0, self.n_latent), device=logits.device, generator=generator)
 
         logits = self.sanitize_tensor(self.param_dict["q_mask_logits"])
         dists["q_mask"] = GumbelSoftmaxBernoulliStraightThrough(temperature=self.gs_temperature, logits=logits)
-        if "mask" not in cv:
-            samples["mask"] = dists["q_mask"].rsample((P,), uniforms=noise.get("u_mask"))
+        T, L = self.n_treatments, self.n_latent
+        slab = T
+        if not torch.is_grad_enabled() and logits.is_cuda and P * T > MAX_PLATED_ROWS:
+            slab = max(1, MAX_PLATED_ROWS // P)
+        if slab >= T:
+            if "mask" not in cv:
+                samples["mask"] = dists["q_mask"].rsample((P,), uniforms=uniforms(0, T))
+            else:
+                samples["mask"] = cv["mask"]
+            dists["q_E"] = self._embedding_dist(samples["mask"], 0)
+            samples["E"] = cv["E"] if "E" in cv else rsample(dists["q_E"], "eps_E")
         else:
-            samples["mask"] = cv["mask"]
-
-        one_hot = self.treatment_one_hot.unsqueeze(0).expand(P, -1, -1)
-        dists["q_E"] = self.embedding_encoder(torch.cat([samples["mask"], one_hot], dim=-1))
-        samples["E"] = cv["E"] if "E" in cv else rsample(dists["q_E"], "eps_E")
+            # inference with many treatments: q(M), q(E|M) in slabs of treatments (every (particle, treatment) row
+            # is independent: correlated_normal_guide.py:132-160 row by row); only the samples are kept, the
+            # Normal's parameters of all T would be two more (P, T, L) tensors
+            mask = torch.empty((P, T, L), device=logits.device) if "mask" not in cv else cv["mask"]
+            E = torch.empty((P, T, L), device=logits.device) if "E" not in cv else cv["E"]
+            for t0 in range(0, T, slab):
+                t1 = min(T, t0 + slab)
+                if "mask" not in cv:
+                    q = GumbelSoftmaxBernoulliStraightThrough(temperature=self.gs_temperature, logits=logits[t0:t1])
+                    mask[:, t0:t1] = q.rsample((P,), uniforms=uniforms(t0, t1))
+                if "E" not in cv:
+                    qE = self._embedding_dist(mask[:, t0:t1], t0)
+                    eps = noise["eps_E"][:, t0:t1] if "eps_E" in noise else torch.randn(
+                        qE.mean.shape, device=logits.device, generator=generator)
+                    E[:, t0:t1] = qE.mean + qE.stddev * eps
+            samples["mask"], samples["E"] = mask, E  # (no dists["q_E"] in this mode: no caller of the inference path reads it)
 
         dists["q_qc_E"] = self.qc_encoder(self.qc_encoder_input.unsqueeze(0).expand(P, -1, -1))
         samples["qc_E"] = cv["qc_E"] if "qc_E" in cv else rsample(dists["q_qc_E"], "eps_qc_E")
 
         if X is not None and D is not None and qc is not None:
             xn = self.normalization_module(X)
-            latent_offset = torch.matmul(D, samples["mask"] * samples["E"])
-            latent_qc_offset = torch.matmul(qc, samples["qc_E"])
-            latent_qc_cf_offset = torch.matmul(1 - qc, samples["qc_E"])
+            latent_offset = self.dosage_product(D, samples["mask"] * samples["E"], P)
+            latent_qc_offset = self.qc_product(qc, samples["qc_E"], P)
+            latent_qc_cf_offset = self.qc_product(1 - qc, samples["qc_E"], P)
             if not torch.is_grad_enabled() and X.is_cuda and latent_offset.dim() == 3:
                 # inference (predictor, validation): x W_x^T once per cell, not once per (particle, cell) row
                 # and per encoder pass -- SURVEY 8a restructuring (ii)
@@ -150,3 +196,28 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
         if "z_basal" in cv:
             samples["z_basal"] = cv["z_basal"]
         return dists, samples
+
+    # ------------------------------------------------------------------ pieces
+    def _embedding_dist(self, mask: torch.Tensor, t0: int) -> torch.distributions.Normal:
+        """q(E | M) for the treatments t0 .. t0 + mask.shape[1] - 1 (correlated_normal_guide.py:147-157).  The
+        reference feeds [mask | one_hot(t)] to the encoder: a (P T) x (L + T) input and a GEMM against eye(T); here
+        the one-hot block of the first layer is a lookup of its weight columns (exact)."""
+        enc = self.embedding_encoder
+        lins = enc.mlp.linears()
+        h = F_hip.onehot_linear(mask, lins[0].weight, lins[0].bias, t0)
+        return enc.forward_from_hidden(h, first_layer_done=True)
+
+    def dosage_product(self, D: torch.Tensor, table: torch.Tensor, P: int) -> torch.Tensor:
+        """torch.matmul(D, table) for dosages D (N, T) and table (P, T, L) (correlated_normal_guide.py:186-188)
+        through the <= max_dosages_per_cell non-zeros of each row."""
+        if self.dense_dosage_matmul:  # the caller saw dosage_overflow: a cell with more dosages than planned for
+            return torch.matmul(D, table)
+        plan = F_hip.DosagePlan(D, self.max_dosages_per_cell)
+        self.dosage_overflow = plan.overflow if self.dosage_overflow is None else self.dosage_overflow | plan.overflow
+        return F_hip.dosage_matmul(plan, table, P)
+
+    @staticmethod
+    def qc_product(qc: torch.Tensor, table: torch.Tensor, P: int) -> torch.Tensor:
+        """torch.matmul(qc, qc_E) for qc (N, Q), Q small (correlated_normal_guide.py:189-194): every column counts."""
+        plan = F_hip.DosagePlan(qc, qc.shape[1])
+        return F_hip.dosage_matmul(plan, table, P)

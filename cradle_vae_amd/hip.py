@@ -53,6 +53,11 @@ PROTOTYPES = {
     "cradle_gemm_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
     "cradle_gemm_tune": (None, [i32, i32, i32, i32, i32, i32]),
     "cradle_gemm_f32_repeat": (i32, [ctypes.c_void_p, c_float_p, i64, i32, c_stream]),
+    "cradle_dosage_rows": (i32, [c_float_p, i32, i32, i32, ctypes.c_void_p, c_float_p, ctypes.c_void_p, c_stream]),
+    "cradle_gather_sum": (i32, [c_float_p, i64, i64, ctypes.c_void_p, c_float_p, i32, i32, i32, i32, c_float_p, i64, i64,
+                                c_stream]),
+    "cradle_scatter_sum": (i32, [c_float_p, i64, i64, ctypes.c_void_p, c_float_p, i32, i32, i32, i32, i32, c_float_p, i64,
+                                 i64, c_stream]),
     "cradle_elbo_step_workspace_bytes": (i64, [ctypes.c_void_p]),
     "cradle_elbo_step": (i32, [ctypes.c_void_p, c_stream]),
     "cradle_step_debug_stop_after": (None, [i32]),

@@ -138,6 +138,7 @@ class PerturbationPlatedELBOLossModule(torch.nn.Module):
 
         batch_elbo = sum(loss_terms.values())
         loss = -batch_elbo.mean() + kl_loss
+        self._check_dosage_overflow()
         # one device->host transfer for all metrics instead of the reference's five (:182-184)
         stacked = torch.stack([-v.detach().mean() for v in loss_terms.values()]).cpu()
         metrics = {f"loss_term_{k}": stacked[i] for i, k in enumerate(loss_terms)}
@@ -152,13 +153,34 @@ class PerturbationPlatedELBOLossModule(torch.nn.Module):
         return torch.mean(
             -0.5 * torch.sum(1.0 + logvar1 - logvar2 - (mu1 - mu2) ** 2 - (logvar1 - logvar2).exp(), dim=1), dim=0)
 
-    @staticmethod
-    def _compute_reweighted_perturbation_plated_loss_term(conditioning_variable, total_obs_per_condition, loss_term):
-        """loss_modules.py:200-232."""
+    def _check_dosage_overflow(self):
+        """One look (one sync) per loss call at the flag the gather-based dosage products raise."""
+        flags = [m.dosage_overflow for m in (self.guide, self.model) if getattr(m, "dosage_overflow", None) is not None]
+        for m in (self.guide, self.model):
+            m.dosage_overflow = None
+        if flags and any(int(f.item()) & 1 for f in flags):
+            raise RuntimeError(
+                f"a cell has more than max_dosages_per_cell={self.guide.max_dosages_per_cell} non-zero dosages: raise "
+                "guide/model.max_dosages_per_cell or set their dense_dosage_matmul = True")
+
+    def _compute_reweighted_perturbation_plated_loss_term(self, conditioning_variable, total_obs_per_condition, loss_term):
+        """loss_modules.py:200-232: matmul((cond != 0) / obs, loss_term), through the non-zeros of each row."""
+        from . import functional as F_hip
+
         condition_nonzero = (conditioning_variable != 0).type(torch.float32)
         obs_scaling = 1 / total_obs_per_condition
         obs_scaling = torch.where(torch.isinf(obs_scaling), torch.zeros_like(obs_scaling), obs_scaling).reshape(1, -1)
-        return torch.matmul(condition_nonzero * obs_scaling, loss_term)
+        weights = condition_nonzero * obs_scaling
+        C = weights.shape[1]
+        kmax = C if C <= 8 else self.guide.max_dosages_per_cell
+        if getattr(self.guide, "dense_dosage_matmul", False):
+            return torch.matmul(weights, loss_term)
+        # entries whose weight is zero (obs count 0 -> inf -> 0) drop out of the plan: they add nothing either way
+        plan = F_hip.DosagePlan(weights, kmax)
+        if C > 8:
+            self.guide.dosage_overflow = (plan.overflow if self.guide.dosage_overflow is None
+                                          else self.guide.dosage_overflow | plan.overflow)
+        return F_hip.dosage_matmul(plan, loss_term, loss_term.shape[0])
 
 
 class cradle_vae_ELBOLossModule(PerturbationPlatedELBOLossModule):

@@ -69,6 +69,19 @@ class GaussianLikelihoodResidualMLP(nn.Module):
         mean, var = self.mean_var(x)
         return torch.distributions.Normal(mean, var.sqrt(), validate_args=False)
 
+    def forward_from_hidden(self, h: torch.Tensor, first_layer_done: bool = True) -> torch.distributions.Normal:
+        """The rest of forward() given the first trunk layer's output h (..., H) (the caller evaluated that layer
+        in a cheaper form: guide._embedding_dist)."""
+        shape = h.shape
+        z = h.reshape(-1, shape[-1])
+        for lin in self.mlp.linears()[1 if first_layer_done else 0:]:
+            z = F_hip.linear(z, lin.weight, lin.bias, act=True, residual=z)
+        mean = F_hip.linear(z, self.mean_encoder.weight, self.mean_encoder.bias)
+        var = torch.exp(F_hip.linear(z, self.log_var_encoder.weight, self.log_var_encoder.bias)) + self.var_eps
+        mean = nan_to_num_ref(mean.reshape(*shape[:-1], -1))
+        var = nan_to_num_ref(torch.abs(var.reshape(*shape[:-1], -1)))
+        return torch.distributions.Normal(mean, var.sqrt(), validate_args=False)
+
     # ---- inference form for inputs [x_shared | tail] whose first block is the same for every particle
     # (the basal encoder reads [log-standardised X | latent offset | qc offset], correlated_normal_guide.py:
     # 190-204): x W_x^T is computed once per cell and enters the (P*n)-row product of the tail as a

@@ -33,6 +33,9 @@ class cradle_vae_Model(torch.nn.Module):
         self.decoder_n_layers = decoder_n_layers
         self.decoder_n_hidden = decoder_n_hidden
         self.sum_mode = sum_mode
+        self.max_dosages_per_cell = 8  # see guide.dosage_product
+        self.dense_dosage_matmul = False
+        self.dosage_overflow = None
         # model.py:33-44
         self.register_buffer("p_E_loc", torch.zeros((n_treatments, n_latent)))
         self.register_buffer("p_E_scale", embedding_prior_scale * torch.ones((n_treatments, n_latent)))
@@ -50,6 +53,16 @@ class cradle_vae_Model(torch.nn.Module):
 
     def get_var_keys(self) -> List[str]:
         return ["z_basal", "E", "mask", "qc_E"]
+
+    def dosage_product(self, D: torch.Tensor, table: torch.Tensor, P: int) -> torch.Tensor:
+        """torch.matmul(D, E * mask) (model.py:118-122) through the non-zero dosages of each row."""
+        from . import functional as F_hip
+
+        if self.dense_dosage_matmul:  # the caller saw dosage_overflow
+            return torch.matmul(D, table)
+        plan = F_hip.DosagePlan(D, self.max_dosages_per_cell)
+        self.dosage_overflow = plan.overflow if self.dosage_overflow is None else self.dosage_overflow | plan.overflow
+        return F_hip.dosage_matmul(plan, table, P)
 
     def forward(
         self,
@@ -82,18 +95,17 @@ class cradle_vae_Model(torch.nn.Module):
             else:
                 samples[k] = dists[f"p_{k}"].sample((n_particles,))
 
-        off = torch.matmul(D, samples["E"] * samples["mask"])
+        off = self.dosage_product(D, samples["E"] * samples["mask"], n_particles)
         if qc is None:
             raise NotImplementedError("qc=None (model.py:134-142) is not used by any caller of the reference")
+        # matmul(ones(n, Q), qc_E) = sum of the Q rows for every cell; matmul(zeros(n, Q), qc_E) = 0
+        shift = samples["qc_E"].sum(dim=1, keepdim=True).expand(-1, n, -1)
         if self.sum_mode:  # model.py:117-119
-            shift = torch.matmul(torch.ones_like(qc), samples["qc_E"])
             z_good = samples["z_basal"] + off
             z_bad = z_good + shift
         else:  # model.py:120-122
-            zero = torch.matmul(torch.zeros_like(qc), samples["qc_E"])
-            one = torch.matmul(torch.ones_like(qc), samples["qc_E"])
-            z_good = torch.cat([samples["z_basal"], off, zero], dim=-1)
-            z_bad = torch.cat([samples["z_basal"], off, one], dim=-1)
+            z_good = torch.cat([samples["z_basal"], off, torch.zeros_like(shift)], dim=-1)
+            z_bad = torch.cat([samples["z_basal"], off, shift], dim=-1)
         lib = cv["library_size"]
         if live_variant is not None:
             # qc in {0,1}: a cell's likelihood weight sits on one variant only (loss_modules.py:142,

@@ -139,6 +139,59 @@ def _sample_workspace(device, floats: int) -> torch.Tensor:
     return ws
 
 
+def dosage_rows(D: torch.Tensor, kmax: int, flags: Optional[torch.Tensor] = None):
+    """Dense (N, T) dosage / indicator matrix -> ELL rows (idx (N, kmax) int32, val (N, kmax)); ``flags`` (int32
+    device word) gets bit 0 OR-ed in when a row has more than kmax non-zeros."""
+    if D.dim() != 2:
+        raise hip.CradleHipError("dosage_rows: expected a 2-D matrix")
+    D = D.contiguous().float()
+    N, T = D.shape
+    kmax = max(1, min(int(kmax), T, 64))
+    idx = torch.empty((N, kmax), device=D.device, dtype=torch.int32)
+    val = torch.empty((N, kmax), device=D.device, dtype=torch.float32)
+    if flags is None:
+        flags = torch.zeros(1, device=D.device, dtype=torch.int32)
+    hip.check(hip.load().cradle_dosage_rows(hip.ptr(D), N, T, kmax, idx.data_ptr(), hip.ptr(val), flags.data_ptr(),
+                                            hip.stream()), "dosage_rows")
+    return idx, val, flags
+
+
+def _table_strides(table: torch.Tensor, P: int):
+    """(stride_p, stride_t) of a (T, L) or (P, T, L) table whose rows are contiguous."""
+    if table.stride(-1) != 1 or table.dtype != torch.float32 or not table.is_cuda:
+        raise hip.CradleHipError("gather/scatter tables must be fp32 CUDA tensors with contiguous rows")
+    if table.dim() == 2:
+        return 0, table.stride(0)
+    if table.dim() == 3 and table.shape[0] in (1, P):
+        return (0 if table.shape[0] == 1 and P > 1 else table.stride(0)), table.stride(1)
+    raise hip.CradleHipError(f"table of shape {tuple(table.shape)} does not broadcast to {P} particles")
+
+
+def gather_sum(table: torch.Tensor, idx: torch.Tensor, val: torch.Tensor, P: Optional[int] = None) -> torch.Tensor:
+    """out[p, n, :] = sum_k val[n, k] * table[p, idx[n, k], :]  -> (P, N, L)."""
+    if P is None:
+        P = table.shape[0] if table.dim() == 3 else 1
+    sp, st = _table_strides(table, P)
+    N, kmax = idx.shape
+    L = table.shape[-1]
+    out = torch.empty((P, N, L), device=table.device, dtype=torch.float32)
+    hip.check(hip.load().cradle_gather_sum(table.data_ptr(), sp, st, idx.data_ptr(), hip.ptr(val), P, N, kmax, L,
+                                           hip.ptr(out), out.stride(0), out.stride(1), hip.stream()), "gather_sum")
+    return out
+
+
+def scatter_sum(dout: torch.Tensor, idx: torch.Tensor, val: torch.Tensor, T: int) -> torch.Tensor:
+    """dtable[p, t, :] = sum over (n, k) with idx[n, k] == t of val[n, k] * dout[p, n, :]  -> (P, T, L)."""
+    dout = dout.contiguous()
+    P, N, L = dout.shape
+    kmax = idx.shape[1]
+    dtable = torch.empty((P, T, L), device=dout.device, dtype=torch.float32)
+    hip.check(hip.load().cradle_scatter_sum(hip.ptr(dout), dout.stride(0), dout.stride(1), idx.data_ptr(), hip.ptr(val), P, N,
+                                            kmax, T, L, hip.ptr(dtable), dtable.stride(0), dtable.stride(1), hip.stream()),
+              "scatter_sum")
+    return dtable
+
+
 NT, NN, TN = 0, 1, 2
 
 

@@ -136,6 +136,7 @@ class PerturbationPlatedPredictor(nn.Module):
             loaders = [loaders]
         device = self._get_device()
         self._nonbinary_qc = None
+        self.guide.dosage_overflow = self.model.dosage_overflow = None
         _, guide_samples = self.guide(n_particles=n_particles, noise=noise)  # :104
         plated = {k: guide_samples[k] for k in self.perturbation_plated_variables}
         id_list, iwelbo_list = [], []
@@ -153,6 +154,14 @@ class PerturbationPlatedPredictor(nn.Module):
                 iwelbo_list.append(self.iwelbo_batch(batch, plated, n_particles, nz))
             idx_curr = torch.cat(idx_list_curr).cpu().numpy() if idx_list_curr else np.zeros((0,), dtype=np.int64)
             id_list.append(loader.dataset.convert_idx_to_ids(idx_curr))
+        over = [m.dosage_overflow for m in (self.guide, self.model) if m.dosage_overflow is not None]
+        if over and any(int(f.item()) & 1 for f in over) and not self.guide.dense_dosage_matmul:
+            # a cell with more non-zero dosages than the gathers planned for: redo with dense products
+            self.guide.dense_dosage_matmul = self.model.dense_dosage_matmul = True
+            try:
+                return self.compute_predictive_iwelbo(loaders, n_particles, noise)
+            finally:
+                self.guide.dense_dosage_matmul = self.model.dense_dosage_matmul = False
         if self.live_variant_only and self._nonbinary_qc is not None and bool(self._nonbinary_qc):
             self.live_variant_only = False  # fractional qc weights both variants: score both
             try:
@@ -172,33 +181,58 @@ class PerturbationPlatedPredictor(nn.Module):
         condition_values: Optional[Dict[str, torch.Tensor]] = None,
         x_var_info: Optional[pd.DataFrame] = None,
         qc=None,
+        *,
+        sampler: Literal["nb", "mean"] = "nb",
+        noise: Optional[Dict[str, torch.Tensor]] = None,
+        particle_idx: Literal["reference", "particle"] = "reference",
+        seed: Optional[int] = None,
     ):
         """predictor.py:202-273 -> (adata_good, adata_bad); rows ordered perturbation-major
         (all particles of dosage 0, then dosage 1, ...) like the reference's concatenation.
 
         All dosages are decoded in one pass and drawn by one sampler launch per variant instead
-        of the reference's per-dosage loop (:239-245)."""
+        of the reference's per-dosage loop (:239-245); each dosage still gets its own prior draw of
+        ``z_basal`` (model.py:112), as in the reference's per-dosage model calls.
+
+        ``particle_idx="reference"`` (default) writes what the reference writes into that column,
+        ``np.tile(np.arange(n_dosages), n_particles)`` (:251 -- a dosage counter); ``"particle"`` writes the
+        particle index the column name promises.  ``sampler="mean"`` replaces the count draw by the distribution
+        mean and ``noise`` (u_mask, eps_E, eps_qc_E (P, ...), z (n_dosages, P, 1, L)) injects the latent draws:
+        the deterministic form the golden fixture pins against the reference."""
         device = self._get_device()
         dosages = dosages.to(device=device, dtype=torch.float32)
         qc = qc.to(device=device, dtype=torch.float32)
-        _, guide_samples = self.guide(n_particles=n_particles)
+        noise = {} if noise is None else {k: v.to(device=device, dtype=torch.float32) for k, v in noise.items()}
+        _, guide_samples = self.guide(n_particles=n_particles, noise=noise)  # :230
         cv = {} if condition_values is None else {k: v.to(device) for k, v in condition_values.items()}
         for var_name in self.perturbation_plated_variables:
             cv[var_name] = guide_samples[var_name]
         n = dosages.shape[0]
+        if "z" in noise:  # per-dosage prior draws (n, P, 1, L) -> (P, n, L)
+            cv["z_basal"] = noise["z"][:, :, 0, :].permute(1, 0, 2).contiguous()
         qc_rows = qc.expand(n, -1) if qc.shape[0] == 1 else qc
-        dists, _ = self.model(D=dosages, qc=qc_rows, condition_values=cv, n_particles=n_particles, sample_x=False)
+        k = int((dosages != 0).sum(dim=1).max().item()) if dosages.numel() else 1
+        dense0, kmax0 = self.model.dense_dosage_matmul, self.model.max_dosages_per_cell
+        self.model.dense_dosage_matmul, self.model.max_dosages_per_cell = dense0 or k > 64, max(kmax0, min(k, 64))
+        try:
+            dists, _ = self.model(D=dosages, qc=qc_rows, condition_values=cv, n_particles=n_particles, sample_x=False)
+        finally:
+            self.model.dense_dosage_matmul, self.model.max_dosages_per_cell = dense0, kmax0
         out = []
-        for key in ("p_x_good", "p_x_bad"):
-            x = dists[key].sample()  # (P, n, G)
+        for j, key in enumerate(("p_x_good", "p_x_bad")):
+            if sampler == "mean":
+                x = dists[key].mean
+            else:
+                x = dists[key].sample(seed=None if seed is None else 2 * seed + j)  # (P, n, G)
             out.append(x.permute(1, 0, 2).reshape(n * n_particles, -1).cpu().numpy())
         adatas = []
         for x in out:
             obs = pd.DataFrame(index=np.arange(x.shape[0]))
             obs["perturbation_idx"] = np.repeat(np.arange(n), n_particles)
-            # the reference writes np.tile(np.arange(n_dosages), n_particles) here (:251), which
-            # labels rows with a dosage counter; the particle index is what the column name says
-            obs["particle_idx"] = np.tile(np.arange(n_particles), n)
+            if particle_idx == "reference":
+                obs["particle_idx"] = np.tile(np.arange(n), n_particles)  # as written at predictor.py:251
+            else:
+                obs["particle_idx"] = np.tile(np.arange(n_particles), n)
             if perturbation_names is not None:
                 obs["perturbation_name"] = np.array(perturbation_names)[obs["perturbation_idx"].to_numpy()]
             adatas.append(make_anndata(x, obs=obs, var=x_var_info.copy() if x_var_info is not None else None))

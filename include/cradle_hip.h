@@ -144,6 +144,29 @@ void cradle_gemm_tune(int tm, int tn, int bk, int depth, int wk, int splitk);
 int cradle_gemm_f32_repeat(const cradle_gemm_desc* desc, float* workspace, int64_t workspace_floats, int repeat,
                            cradle_stream_t stream);
 
+/* ---- K4: matmul(D, .) through the non-zeros of D ------------------------------------------
+ * Replaces the dense dosage products of the module-level API: torch.matmul(D, E * mask) and matmul(qc, qc_E) at
+ * cradle_vae/models/cradle_vae/guides/correlated_normal_guide.py:186-194 and models/cradle_vae/model.py:118-122,
+ * the plated re-weighting matmul of models/utils/loss_modules.py:224-232, and the per-perturbation model calls of
+ * analysis/average_treatment_effects.py:157-162,183-188.  D (N, T) has at most a few non-zeros per row
+ * (data/norman/data_module.py:100-102).
+ *   cradle_dosage_rows : dense D (N, T), contiguous -> ELL rows: ell_idx (N, kmax) treatment index ascending, -1 = none;
+ *                        ell_val (N, kmax).  *flags |= 1 if a row holds more than kmax non-zeros (the caller zeroes it
+ *                        and falls back to a dense product).
+ *   cradle_gather_sum  : out[p, n, :] = sum_k ell_val[n, k] * table[p, ell_idx[n, k], :]     (forward)
+ *   cradle_scatter_sum : dtable[p, t, :] = sum_{(n,k): ell_idx[n,k] == t} ell_val[n, k] * dout[p, n, :]  (its transpose,
+ *                        for autograd; entries are added in (n, k) order: deterministic)
+ * table / dtable: (P, T, L) with element strides (stride_p, stride_t), rows contiguous; out / dout: (P, N, L) with
+ * strides (out_stride_p, out_stride_n).  stride_p = 0 broadcasts one table to all particles. */
+int cradle_dosage_rows(const float* D, int N, int T, int kmax, int* ell_idx, float* ell_val, int* flags,
+                       cradle_stream_t stream);
+int cradle_gather_sum(const float* table, int64_t stride_p, int64_t stride_t, const int* ell_idx, const float* ell_val,
+                      int P, int N, int kmax, int L, float* out, int64_t out_stride_p, int64_t out_stride_n,
+                      cradle_stream_t stream);
+int cradle_scatter_sum(const float* dout, int64_t out_stride_p, int64_t out_stride_n, const int* ell_idx,
+                       const float* ell_val, int P, int N, int kmax, int T, int L, float* dtable, int64_t stride_p,
+                       int64_t stride_t, cradle_stream_t stream);
+
 /* ---- The fused ELBO step ---------------------------------------------------------------
  * Forward + backward of PerturbationPlatedELBOLossModule.loss
  * (cradle_vae/models/utils/loss_modules.py:54-187: guide(X,qc) -> model -> guide(cfX,1-qc),

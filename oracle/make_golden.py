@@ -202,6 +202,28 @@ def ate_iwelbo_case(name, shape, seed, n_alt=4, ate_particles=12, ate_chunk=8, i
     for k, v in plated.items():
         out[f"iwelbo/noise/{k}"] = v.numpy()
     out["iwelbo/noise/eps_z"] = eps_z.numpy()
+
+    # ---------------- sample_observations (models/utils/predictor.py:202-273) ----------------
+    # count sampler in "mean" mode (pyro's sampler is not in the reference); per-dosage prior draws of z_basal
+    # injected.  (noise drawn after everything above: the earlier sections of the fixture keep their values)
+    Ps = 3
+    D_obs = torch.cat([D_ctl, D_alt])
+    so = dict(u_mask=torch.rand(Ps, T, L, generator=g), eps_E=torch.randn(Ps, T, L, generator=g),
+              eps_qc_E=torch.randn(Ps, Q, L, generator=g), z=torch.randn(D_obs.shape[0], Ps, 1, L, generator=g))
+    queue = rh.guide_noise_queue(so, with_z=False) + [("normal", so["z"][i]) for i in range(D_obs.shape[0])]
+    names = [f"pert{i}" for i in range(D_obs.shape[0])]
+    with rh.injected_noise(queue) as rest:
+        good, bad = predictor.sample_observations(
+            dosages=D_obs, perturbation_names=names, n_particles=Ps,
+            condition_values=dict(library_size=lib.clone()), qc=torch.ones(1, Q))
+        assert not rest
+    out["samples/good"], out["samples/bad"] = np.asarray(good.X), np.asarray(bad.X)
+    out["samples/perturbation_idx"] = good.obs["perturbation_idx"].to_numpy()
+    out["samples/particle_idx"] = good.obs["particle_idx"].to_numpy()
+    out["samples/n_particles"] = np.array(Ps)
+    out["samples/dosages"] = D_obs.numpy()
+    for k, v in so.items():
+        out[f"samples/noise/{k}"] = v.numpy()
     path = os.path.join(GOLDEN, f"predictor_{name}.npz")
     np.savez_compressed(path, **out)
     print(f"{path}: ({os.path.getsize(path)} B)")
@@ -267,6 +289,9 @@ def main():
     rh._GammaPoisson.SAMPLE_MODE = "mean"
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":  # only the analysis-helper fixture
         metrics_case()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "predictor":  # only the predictor fixture
+        ate_iwelbo_case("tiny", syn.TINY, 9)
         return
     T = syn.TINY
     elbo_case("tiny", T, 1)

@@ -46,4 +46,5 @@ def load_predictor(name, dtype=torch.float32, device="cpu"):
         case[grp] = _group(z, grp, dtype, device)
     case["ate"] = _group(z, "ate", dtype, device)
     case["iwelbo"] = _group(z, "iwelbo", dtype, device)
+    case["samples"] = _group(z, "samples", dtype, device)
     return case

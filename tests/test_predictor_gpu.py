@@ -99,6 +99,44 @@ def test_ate_matches_reference(method):
     np.testing.assert_allclose(res.X, ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()))
 
 
+def test_sample_observations_matches_reference():
+    """predictor.sample_observations against the reference's own output (count sampler in mean mode, latent
+    draws injected): values, row order, and the obs columns exactly as the reference writes them -- including
+    its particle_idx column, which holds a dosage counter (predictor.py:251); the particle index is opt-in."""
+    case = gio.load_predictor("tiny", torch.float32, DEV)
+    pred = _predictor(case)
+    so = case["samples"]
+    P = int(so["n_particles"])
+    noise = {k[len("noise/"):]: v for k, v in so.items() if k.startswith("noise/")}
+    Q = case["cfg"]["n_qc"]
+    names = [f"pert{i}" for i in range(so["dosages"].shape[0])]
+    kw = dict(dosages=so["dosages"], perturbation_names=names, n_particles=P,
+              condition_values=dict(library_size=1e4 * torch.ones(1)), qc=torch.ones(1, Q), sampler="mean", noise=noise)
+    good, bad = pred.sample_observations(**kw)
+    for got, ref in ((good, so["good"]), (bad, so["bad"])):
+        ref = ref.cpu().numpy()
+        np.testing.assert_allclose(got.X, ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()))
+        assert np.array_equal(got.obs["perturbation_idx"].to_numpy(), so["perturbation_idx"].cpu().numpy())
+        assert np.array_equal(got.obs["particle_idx"].to_numpy(), so["particle_idx"].cpu().numpy())
+        assert list(got.obs["perturbation_name"][:P + 1]) == ["pert0"] * P + ["pert1"]
+    assert not np.allclose(good.X, bad.X)
+    fixed, _ = pred.sample_observations(particle_idx="particle", **kw)
+    assert list(fixed.obs["particle_idx"][:2 * P]) == list(range(P)) * 2
+
+
+def test_iwelbo_falls_back_to_dense_products_when_a_cell_has_more_dosages_than_planned():
+    case = gio.load_predictor("tiny", torch.float32, DEV)
+    pred = _predictor(case)
+    iw = case["iwelbo"]
+    P, bs = int(iw["n_particles"]), int(iw["batch"])
+    noise = {k[len("noise/"):]: v for k, v in iw.items() if k.startswith("noise/")}
+    assert int((case["batch"]["D"] != 0).sum(1).max()) >= 2
+    pred.guide.max_dosages_per_cell = pred.model.max_dosages_per_cell = 1  # two-guide cells overflow the plan
+    df = pred.compute_predictive_iwelbo(_Loader(case["batch"], bs), n_particles=P, noise=noise)
+    assert not pred.guide.dense_dosage_matmul  # restored after the dense re-run
+    np.testing.assert_allclose(df["IWELBO"].to_numpy(), iw["values"].cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
 def _sampler_inputs(P, C, G, seed=0):
     g = torch.Generator().manual_seed(seed)
     logits = (2.0 * torch.randn(P * C, G, generator=g)).to(DEV)
@@ -265,6 +303,7 @@ def test_sample_observations_and_sampled_ate_statistics():
     assert good.X.shape == (3 * n, case["cfg"]["n_phenos"]) == bad.X.shape
     assert (good.X >= 0).all() and np.array_equal(good.X, np.round(good.X))
     assert list(good.obs["perturbation_idx"][:4]) == [0, 0, 0, 1]
+    assert list(good.obs["particle_idx"][:4]) == [0, 1, 2, 3]  # the reference's column (predictor.py:251)
 
 
 def test_sampler_draws_do_not_depend_on_the_particle_split():
@@ -290,3 +329,99 @@ def test_sampler_draws_do_not_depend_on_the_particle_split():
         outs.append((sums.clone(), samples.clone()))
     assert torch.equal(outs[0][1], outs[1][1])
     assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-4)
+
+
+def _ate_setup(T, G, L, H, n_alt, seed):
+    """Random-weight model/guide of the given size and a set of one- and two-guide perturbations."""
+    from cradle_vae_amd import synthetic as syn
+    from oracle import cradle_oracle as co
+
+    g = torch.Generator().manual_seed(seed)
+    cfg = dict(n_latent=L, n_treatments=T, n_phenos=G, n_qc=1, decoder_n_layers=1, decoder_n_hidden=H,
+               basal_encoder_n_layers=1, basal_encoder_n_hidden=H, embedding_encoder_n_layers=4, embedding_encoder_n_hidden=H,
+               mask_prior_prob=0.01, embedding_prior_scale=1.0, beta=0.5, alpha=None, n_particles=1)
+    params = co.init_params(**{k: cfg[k] for k in cfg if k not in ("beta", "alpha", "n_particles")}, seed=seed,
+                            log_x_mean=torch.zeros(G), log_x_std=torch.ones(G))
+    if T > 4096:
+        params.pop("guide.treatment_one_hot")  # eye(T): 400 MB at 10 k treatments, not a buffer of the module there
+    D_alt = torch.zeros(n_alt, T)
+    a, b = torch.randint(0, T, (n_alt,), generator=g), torch.randint(0, T, (n_alt,), generator=g)
+    D_alt[torch.arange(n_alt), a] = 1.0
+    two = torch.rand(n_alt, generator=g) < 0.4
+    D_alt[torch.arange(n_alt)[two], b[two]] = 1.0
+    D_ctl = torch.zeros(1, T)
+    D_ctl[0, 0] = 1.0
+    return cfg, params, D_ctl, D_alt
+
+
+@pytest.mark.parametrize("method", ["mean", "perturbseq"])
+def test_ate_gather_and_slab_path_equals_dense_oracle(method, monkeypatch):
+    """The module path without the O(T^2) one-hot and without dense matmul(D, .): embedding encoder through the
+    column lookup, evaluated in slabs of treatments, offsets through the dosage plan -- against the oracle, which
+    does what the reference does (eye(T) input, dense products), on the same injected draws."""
+    from cradle_vae_amd import guide as guide_mod
+    from cradle_vae_amd.predictor import cradle_vae_Predictor
+    from oracle import cradle_oracle as co
+
+    T, G, L, H, n_alt, c, n_particles = 64, 64, 16, 32, 20, 16, 48
+    cfg, params, D_ctl, D_alt = _ate_setup(T, G, L, H, n_alt, seed=5)
+    g = torch.Generator().manual_seed(77)
+    chunks = []
+    for _ in range(n_particles // c):
+        chunks.append(dict(u_mask=torch.rand(c, T, L, generator=g), eps_E=torch.randn(c, T, L, generator=g),
+                           eps_qc_E=torch.randn(c, 1, L, generator=g), z_control=torch.randn(c, 1, L, generator=g),
+                           z_alt=torch.randn(n_alt, c, 1, L, generator=g)))
+    lib = 1e4 * torch.ones(1)
+    # oracle: dense, as the reference (fp64)
+    p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in params.items()}
+    Xc, Xa = [], []
+    for nz in chunks:
+        n64 = {k: v.double() for k, v in nz.items()}
+        _, s = co.guide_forward(p64, n64, c)
+        s = dict(s)
+        s["z_basal"] = n64["z_control"]
+        Xc.append(co.nb_mean_good(p64, D_ctl.double(), s, lib.double())[:, 0])
+        alt = []
+        for i in range(n_alt):
+            s["z_basal"] = n64["z_alt"][i]
+            alt.append(co.nb_mean_good(p64, D_alt[i:i + 1].double(), s, lib.double())[:, 0])
+        Xa.append(torch.stack(alt))
+    ref = co.ate_from_draws(torch.cat(Xc), torch.cat(Xa, dim=1), method).numpy()
+
+    case = dict(cfg=cfg, params={k: v.to(DEV) for k, v in params.items()})
+    lm = build_loss_module(case)
+    pred = cradle_vae_Predictor(lm.model, lm.guide)
+    kw = dict(dosages_alt=D_alt, dosages_control=D_ctl, quality=torch.ones(1, 1), method=method, n_particles=n_particles,
+              condition_values=dict(library_size=lib), batch_size=c, sampler="mean", noise_chunks=chunks)
+    whole = pred.estimate_average_treatment_effects(**kw).X
+    monkeypatch.setattr(guide_mod, "MAX_PLATED_ROWS", c * 10)  # 16 particles x 64 treatments -> slabs of 10 treatments
+    slabbed = pred.estimate_average_treatment_effects(**kw).X
+    scale = float(np.abs(ref).max())
+    np.testing.assert_allclose(whole, ref, rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(slabbed, ref, rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(slabbed, whole, rtol=1e-6, atol=1e-6 * scale)  # slabs change no row's arithmetic
+
+
+def test_ate_with_ten_thousand_treatments_fits_in_two_gigabytes():
+    """BASELINE config 5's predictor shape: T = 10 000 treatments, G = 8000 genes, 128-particle chunks.  As the
+    reference writes it this needs a (128 * 10 000) x 10 100 one-hot encoder input (52 GB) and a dense
+    (n, 10 000) x (128, 10 000, L) product per call; here the peak stays under 2 GB beyond the parameters."""
+    from cradle_vae_amd.predictor import cradle_vae_Predictor
+
+    T, G, L, H, n_alt, c = 10000, 8000, 100, 400, 96, 128
+    cfg, params, D_ctl, D_alt = _ate_setup(T, G, L, H, n_alt, seed=9)
+    case = dict(cfg=cfg, params={k: v.to(DEV) for k, v in params.items()})
+    lm = build_loss_module(case)
+    del case, params
+    pred = cradle_vae_Predictor(lm.model, lm.guide)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    res = pred.estimate_average_treatment_effects(
+        dosages_alt=D_alt, dosages_control=D_ctl, quality=torch.ones(1, 1), method="perturbseq", n_particles=c,
+        condition_values=dict(library_size=1e4 * torch.ones(1)), batch_size=c, seed=3)
+    torch.cuda.synchronize()
+    extra = torch.cuda.max_memory_allocated() - base
+    assert res.X.shape == (n_alt, G) and np.isfinite(res.X).all() and np.abs(res.X).max() > 0
+    assert extra < 2 * 1024**3, f"{extra / 1024**3:.2f} GiB beyond the module"
