@@ -17,19 +17,107 @@ import numpy as np
 import torch
 
 
-class TensorPerturbationDataset:
-    """perturbation_dataset.py:44-82."""
+class SparseDosage:
+    """A dosage matrix D (n_cells, n_treatments) kept as its non-zeros: per cell ``kmax`` (treatment index,
+    dosage) pairs, index -1 = unused slot, indices ascending.  The reference keeps D dense
+    (perturbation_dataset.py:47-67), which is 160 GB for 4 M cells x 10 k treatments; every cell carries one or
+    two guides (data/norman/data_module.py:100-102).  Rows are densified only for the batch that needs them."""
 
-    def __init__(self, X: torch.Tensor, D: torch.Tensor, qc: torch.Tensor, cfX: Optional[torch.Tensor] = None,
+    def __init__(self, idx: torch.Tensor, val: torch.Tensor, n_treatments: int):
+        assert idx.shape == val.shape and idx.dim() == 2
+        self.idx, self.val, self.n_treatments = idx.to(torch.int32), val.to(torch.float32), int(n_treatments)
+
+    @classmethod
+    def from_dense(cls, D: torch.Tensor, kmax: Optional[int] = None, chunk: int = 1 << 16) -> "SparseDosage":
+        n, T = D.shape
+        if kmax is None:
+            kmax = 1
+            for i in range(0, n, chunk):
+                kmax = max(kmax, int((D[i:i + chunk] != 0).sum(1).max().item())) if n else 1
+        idx = torch.full((n, kmax), -1, dtype=torch.int32, device=D.device)
+        val = torch.zeros((n, kmax), dtype=torch.float32, device=D.device)
+        for i in range(0, n, chunk):
+            blk = D[i:i + chunk]
+            nz = blk != 0
+            if int(nz.sum(1).max().item()) > kmax:
+                raise ValueError(f"a cell has more than kmax={kmax} non-zero dosages")
+            # stable sort puts the non-zero columns first, in ascending column order
+            order = torch.sort((~nz).to(torch.int8), dim=1, stable=True)[1][:, :kmax]
+            v = torch.gather(blk, 1, order).float()
+            keep = v != 0
+            idx[i:i + chunk] = torch.where(keep, order.to(torch.int32), torch.full_like(order, -1, dtype=torch.int32))
+            val[i:i + chunk] = v
+        return cls(idx, val, T)
+
+    @property
+    def shape(self):
+        return (self.idx.shape[0], self.n_treatments)
+
+    @property
+    def device(self):
+        return self.idx.device
+
+    def __len__(self):
+        return self.idx.shape[0]
+
+    def to(self, device=None, **_):
+        return SparseDosage(self.idx.to(device), self.val.to(device), self.n_treatments)
+
+    def rows(self, sel: torch.Tensor) -> "SparseDosage":
+        return SparseDosage(self.idx.index_select(0, sel), self.val.index_select(0, sel), self.n_treatments)
+
+    def dense(self, sel: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Dense fp32 rows (all, or those of the index tensor ``sel``) -- the batch contract's D (N, T)."""
+        idx, val = (self.idx, self.val) if sel is None else (self.idx.index_select(0, sel), self.val.index_select(0, sel))
+        out = torch.zeros((idx.shape[0], self.n_treatments + 1), dtype=torch.float32, device=idx.device)
+        col = torch.where(idx >= 0, idx, torch.full_like(idx, self.n_treatments)).long()  # unused slots -> a spare column
+        out.scatter_(1, col, val)
+        return out[:, :self.n_treatments].contiguous()
+
+    def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)):
+            return self.dense(torch.tensor([int(i)], device=self.device))[0]
+        if isinstance(i, slice):
+            return SparseDosage(self.idx[i], self.val[i], self.n_treatments).dense()
+        return self.dense(torch.as_tensor(i, device=self.device).long())
+
+    def obs_per_dim(self) -> torch.Tensor:
+        """(D != 0).sum(0) (perturbation_dataset.py:64)."""
+        hit = (self.idx >= 0) & (self.val != 0)
+        return torch.bincount(self.idx[hit].long(), minlength=self.n_treatments)
+
+    def max_per_row(self) -> int:
+        return max(1, int(((self.idx >= 0) & (self.val != 0)).sum(1).max().item())) if len(self) else 1
+
+
+def pack_counts(X: torch.Tensor, dtype="auto") -> torch.Tensor:
+    """Count matrices are integer-valued (the reference validates that: pyro GammaPoisson's support): stored as
+    uint8 / int16 / int32 they take a quarter / half of the fp32 footprint and convert back exactly."""
+    if dtype is None or dtype == "fp32" or X.dtype in (torch.uint8, torch.int16, torch.int32):
+        return X
+    if dtype == "auto":
+        if not bool((X == X.round()).all()) or bool((X < 0).any()):
+            return X
+        mx = float(X.max()) if X.numel() else 0.0
+        dtype = torch.uint8 if mx <= 255 else (torch.int16 if mx <= 32767 else (torch.int32 if mx < 2**31 else None))
+        if dtype is None:
+            return X
+    return X.to(dtype)
+
+
+class TensorPerturbationDataset:
+    """perturbation_dataset.py:44-82.  ``D`` may be dense (as in the reference) or a ``SparseDosage``."""
+
+    def __init__(self, X: torch.Tensor, D, qc: torch.Tensor, cfX: Optional[torch.Tensor] = None,
                  ids: Optional[Iterable] = None):
         self.X, self.D, self.qc, self.cfX = X, D, qc, cfX
         self.ids = np.arange(len(X)) if ids is None else np.array(ids)
-        self.D_obs_per_dim = (self.D != 0).sum(0)
+        self.D_obs_per_dim = self.D.obs_per_dim() if isinstance(D, SparseDosage) else (self.D != 0).sum(0)
         self.qc_obs_per_dim = (self.qc != 0).sum(0)
-        self.library_size = self.X.sum(1)
+        self.library_size = self.X.sum(1, dtype=torch.float32) if not self.X.is_floating_point() else self.X.sum(1)
 
     def __getitem__(self, idx) -> Dict[str, torch.Tensor]:
-        return dict(idx=idx, X=self.X[idx], D=self.D[idx], qc=self.qc[idx], cfX=self.cfX[idx])
+        return dict(idx=idx, X=self.X[idx].float(), D=self.D[idx], qc=self.qc[idx], cfX=self.cfX[idx].float())
 
     def __len__(self):
         return len(self.X)
@@ -40,6 +128,8 @@ class TensorPerturbationDataset:
     def max_dosages_per_cell(self) -> int:
         """Largest number of non-zero dosages any cell of this data set carries (Norman: 2, Replogle: 1).
         The fused step sizes its per-cell dosage lists and its compact treatment axis with it."""
+        if getattr(self, "_max_dosages", None) is None and isinstance(self.D, SparseDosage):
+            self._max_dosages = self.D.max_per_row()
         if getattr(self, "_max_dosages", None) is None:
             m = 0
             for i in range(0, self.D.shape[0], 1 << 16):
@@ -66,25 +156,70 @@ class SCRNASeqTensorPerturbationDataset(TensorPerturbationDataset):
 class DeviceBatchLoader:
     """Iterates ``{idx, X, D, qc, cfX, library_size}`` batches gathered on ``device``.
 
-    shuffle: a fresh permutation per epoch from ``seed + epoch`` -- the same on every rank, so
-    the ranks' slices (``perm[rank::world_size]``, truncated to a common length) are disjoint.
+    Storage: counts (``X``, ``cfX``) as the narrowest integer type that holds them (``count_dtype="auto"``;
+    converted to fp32 by the batch gather, exactly), ``D`` as ``SparseDosage`` pairs (densified per batch: the
+    batch contract's dense (N, T)), and -- with ``shard_storage`` (default for more than one rank) -- only this
+    rank's cells: rank r of w keeps cells r, r + w, r + 2w, ... of a seeded permutation and reshuffles within
+    them every epoch, so that 4 M cells x 8 k genes (64 GB per count matrix at 16 bit) cost every one of 8 ranks
+    16 GB rather than 256 GB.  Without ``shard_storage`` every rank holds the whole set and walks its slice of a
+    fresh global permutation per epoch (``perm[rank::world_size]``, truncated to a common length: disjoint).
     """
 
     def __init__(self, dataset: TensorPerturbationDataset, batch_size: int, shuffle: bool = False,
-                 drop_last: bool = False, seed: int = 0, rank: int = 0, world_size: int = 1, device=None):
+                 drop_last: bool = False, seed: int = 0, rank: int = 0, world_size: int = 1, device=None,
+                 shard_storage: Optional[bool] = None, count_dtype="auto", sparse_dosage: bool = True):
         self.dataset = dataset
         self.batch_size, self.shuffle, self.drop_last = batch_size, shuffle, drop_last
         self.seed, self.rank, self.world_size = seed, rank, world_size
         self.device = torch.device(device) if device is not None else dataset.X.device
         self.epoch = 0
+        self.shard_storage = (world_size > 1) if shard_storage is None else bool(shard_storage)
+        n = len(dataset)
+        # cells this rank stores (global indices, ascending within the rank's share of a seeded permutation)
+        if self.shard_storage and world_size > 1:
+            g = torch.Generator().manual_seed(seed)
+            perm = torch.randperm(n, generator=g) if shuffle else torch.arange(n)
+            per_rank = n // world_size if shuffle else (n + world_size - 1) // world_size
+            self.owned = perm[rank::world_size][:per_rank].sort()[0] if shuffle else perm[rank::world_size][:per_rank]
+        else:
+            self.owned = None
+        sel = None if self.owned is None else self.owned.to(dataset.X.device)
+
+        def take(t):
+            return t if sel is None else t.index_select(0, sel.to(t.device))
+
         f32 = dict(device=self.device, dtype=torch.float32)
-        self._t = dict(X=dataset.X.to(**f32), D=dataset.D.to(**f32), qc=dataset.qc.to(**f32),
-                       cfX=dataset.cfX.to(**f32), library_size=dataset.library_size.to(**f32))
+        D = dataset.D
+        if isinstance(D, SparseDosage):
+            Dst = (D if sel is None else D.rows(sel.to(D.device))).to(self.device)
+        elif sparse_dosage:
+            Dst = SparseDosage.from_dense(take(D)).to(self.device)
+        else:
+            Dst = take(D).to(**f32)
+        self._t = dict(X=pack_counts(take(dataset.X), count_dtype).to(self.device), D=Dst,
+                       qc=take(dataset.qc).to(**f32), cfX=pack_counts(take(dataset.cfX), count_dtype).to(self.device),
+                       library_size=take(dataset.library_size).to(**f32))
 
     def set_epoch(self, epoch: int):
         self.epoch = epoch
 
-    def _indices(self) -> torch.Tensor:
+    def stored_bytes(self) -> int:
+        """Bytes this rank keeps resident for the data set."""
+        tot = 0
+        for v in self._t.values():
+            tot += (v.idx.numel() * 4 + v.val.numel() * 4) if isinstance(v, SparseDosage) else v.numel() * v.element_size()
+        return tot
+
+    def _indices(self):
+        """-> (positions into this rank's storage, global cell indices), in iteration order."""
+        if self.owned is not None:
+            m = len(self.owned)
+            if self.shuffle:
+                g = torch.Generator().manual_seed(self.seed + 1000003 * (self.epoch + 1) + self.rank)
+                pos = torch.randperm(m, generator=g)
+            else:
+                pos = torch.arange(m)
+            return pos, self.owned[pos]
         n = len(self.dataset)
         if self.shuffle:
             g = torch.Generator().manual_seed(self.seed + self.epoch)
@@ -94,20 +229,26 @@ class DeviceBatchLoader:
         if self.world_size > 1:
             per_rank = n // self.world_size if self.shuffle else (n + self.world_size - 1) // self.world_size
             perm = perm[self.rank::self.world_size][:per_rank]
-        return perm
+        return perm, perm
 
     def __len__(self):
-        n = len(self._indices())
+        n = len(self._indices()[0])
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
-        idx_all = self._indices()
-        idx_dev = idx_all.to(self.device)
-        n = len(idx_all)
+        pos_all, idx_all = self._indices()
+        pos_dev = pos_all.to(self.device)
+        n = len(pos_all)
         stop = n - n % self.batch_size if self.drop_last else n
         for s in range(0, stop, self.batch_size):
-            sl = idx_dev[s:s + self.batch_size]
-            batch = {k: v.index_select(0, sl) for k, v in self._t.items()}
+            sl = pos_dev[s:s + self.batch_size]
+            batch = {}
+            for k, v in self._t.items():
+                if isinstance(v, SparseDosage):
+                    batch[k] = v.dense(sl)
+                else:
+                    r = v.index_select(0, sl)
+                    batch[k] = r if r.dtype == torch.float32 else r.to(torch.float32)
             batch["idx"] = idx_all[s:s + self.batch_size]
             yield batch
         if self.shuffle:
@@ -187,13 +328,15 @@ class TensorPerturbationDataModule:
         if control_label is not None:
             self.control_label = control_label
         f32 = dict(device=self.device, dtype=torch.float32)
-        self.X, self.D, self.qc = X.to(**f32), D.to(**f32), qc.to(**f32)
+        self.X, self.qc = X.to(**f32), qc.to(**f32)
+        # dosages stay (index, dosage) pairs from here on: dense only per batch (DeviceBatchLoader)
+        self.D = (D if isinstance(D, SparseDosage) else SparseDosage.from_dense(D.to(self.device))).to(self.device)
         n = self.X.shape[0]
         self.obs = pd.DataFrame({"treatment": np.asarray(list(treatments)), "split": np.asarray(list(splits))},
                                 index=[f"cell{i}" for i in range(n)])
         self.obs["total_qc"] = (self.qc.max(dim=1)[0] != 0).cpu().numpy().astype(int)
         self.x_var_info = pd.DataFrame(index=list(x_var_names) if x_var_names is not None else [f"gene{i}" for i in range(self.X.shape[1])])
-        self.d_var_info = pd.DataFrame(index=list(d_var_names) if d_var_names is not None else [f"guide{i}" for i in range(self.D.shape[1])])
+        self.d_var_info = pd.DataFrame(index=list(d_var_names) if d_var_names is not None else [f"guide{i}" for i in range(self.D.shape[1])])  # noqa: E501
         self.qc_var_info = pd.DataFrame(index=list(qc_var_names) if qc_var_names is not None else [f"qc{i}" for i in range(self.qc.shape[1])])
         self.n_qc_fail = int(self.obs["total_qc"].sum())
         self.n_qc_pass = n - self.n_qc_fail
@@ -206,7 +349,7 @@ class TensorPerturbationDataModule:
             di = idx.to(self.device)
             Xs = self.X[di]
             cfX = build_counterfactual_inputs(Xs, codes[idx], self.qc[di].max(dim=1)[0] != 0, generator=gen)
-            self.datasets[split] = SCRNASeqTensorPerturbationDataset(Xs, self.D[di], self.qc[di], cfX, ids=ids[idx.numpy()])
+            self.datasets[split] = SCRNASeqTensorPerturbationDataset(Xs, self.D.rows(di), self.qc[di], cfX, ids=ids[idx.numpy()])
         Xtr = self.datasets["train"].X
         log_mean = batch_log_mean(Xtr)
         self.x_train_statistics = _stats_cls()(

@@ -120,6 +120,36 @@ def _worker(rank, port, results):
         gathered = [torch.empty_like(draw) for _ in range(WORLD)]
         dist.all_gather(gathered, draw)
         assert torch.equal(gathered[0], gathered[1])
+
+        # 5. rank-sharded data storage: each rank keeps (about) half of the cells, the halves are disjoint and
+        #    cover the set, every epoch visits the rank's own cells in a new order, batches equal the source rows
+        from cradle_vae_amd.data import DeviceBatchLoader, SCRNASeqTensorPerturbationDataset, SparseDosage
+
+        g = torch.Generator().manual_seed(0)  # same data set on both ranks
+        n, G, T = 101, 6, 9
+        X = torch.poisson(3 * torch.rand(n, G, generator=g))
+        D = torch.zeros(n, T)
+        D[torch.arange(n), torch.randint(0, T, (n,), generator=g)] = 1.0
+        qc = (torch.rand(n, 1, generator=g) < 0.2).float()
+        ds = SCRNASeqTensorPerturbationDataset(X, SparseDosage.from_dense(D), qc, X.flip(0))
+        whole = DeviceBatchLoader(ds, 8, shuffle=True, seed=2, shard_storage=False, rank=rank, world_size=WORLD)
+        ld = DeviceBatchLoader(ds, 8, shuffle=True, drop_last=True, seed=2, rank=rank, world_size=WORLD)
+        assert ld.shard_storage and ld._t["X"].shape[0] == n // WORLD and ld.stored_bytes() * 2 <= whole.stored_bytes() + 64
+        e0, e1 = [], []
+        for ep in (e0, e1):
+            for bt in ld:
+                i = bt["idx"]
+                assert torch.equal(bt["X"], X[i]) and torch.equal(bt["D"], D[i]) and torch.equal(bt["cfX"], X.flip(0)[i])
+                assert torch.equal(bt["library_size"], X[i].sum(1))
+                ep.append(i)
+        e0, e1 = torch.cat(e0), torch.cat(e1)
+        assert not torch.equal(e0, e1) and set(e0.tolist()) <= set(ld.owned.tolist())
+        owned = torch.full((n // WORLD,), -1, dtype=torch.long)
+        owned[:len(ld.owned)] = ld.owned
+        gathered = [torch.empty_like(owned) for _ in range(WORLD)]
+        dist.all_gather(gathered, owned)
+        a, b2 = set(gathered[0].tolist()), set(gathered[1].tolist())
+        assert not (a & b2) and len(a | b2) == 2 * (n // WORLD)
         results[rank] = "ok"
     except BaseException as e:  # noqa: BLE001
         results[rank] = f"{type(e).__name__}: {e}"

@@ -148,6 +148,57 @@ def test_device_batch_loader_shards_and_gathers():
     assert sorted(torch.cat(ev).tolist()) == list(range(n))
 
 
+def test_sparse_dosage_and_packed_counts_give_the_dense_loaders_batches():
+    """D as (index, dosage) pairs and counts as small integers: same batches, bit for bit, as the dense fp32
+    storage of the reference's TensorPerturbationDataset (perturbation_dataset.py:44-89), at a fraction of it."""
+    from cradle_vae_amd.data import (DeviceBatchLoader, SCRNASeqTensorPerturbationDataset, SparseDosage,
+                                     TensorPerturbationDataModule, pack_counts)
+
+    g = torch.Generator().manual_seed(1)
+    n, G, T = 203, 12, 300
+    X = torch.poisson(40 * torch.rand(n, G, generator=g))
+    X[3, 2] = 70000.0  # forces 32-bit storage for X; cfX fits 8 bit
+    cfX = torch.poisson(3 * torch.rand(n, G, generator=g))
+    cfX[::3] = 0.0
+    D = torch.zeros(n, T)
+    D[torch.arange(n), torch.randint(0, T, (n,), generator=g)] = 1.0
+    two = torch.rand(n, generator=g) < 0.3
+    D[torch.arange(n)[two], torch.randint(0, T, (int(two.sum()),), generator=g)] = 0.5  # fractional dosage survives
+    D[:5] = 0.0  # control cells
+    qc = (torch.rand(n, 1, generator=g) < 0.2).float()
+    sp = SparseDosage.from_dense(D)
+    assert sp.idx.shape == (n, 2) and torch.equal(sp.dense(), D) and torch.equal(sp[7], D[7]) and torch.equal(sp[2:9], D[2:9])
+    assert torch.equal(sp.obs_per_dim(), (D != 0).sum(0)) and sp.max_per_row() == 2
+    with pytest.raises(ValueError):
+        SparseDosage.from_dense(D, kmax=1)
+    assert pack_counts(X).dtype == torch.int32 and pack_counts(cfX).dtype == torch.uint8
+    assert pack_counts(X + 0.5).dtype == torch.float32  # not integer-valued: left alone
+    dense = SCRNASeqTensorPerturbationDataset(X, D, qc, cfX)
+    sparse = SCRNASeqTensorPerturbationDataset(X, sp, qc, cfX)
+    assert torch.equal(sparse.get_dosage_obs_per_dim(), dense.get_dosage_obs_per_dim())
+    assert sparse.max_dosages_per_cell() == dense.max_dosages_per_cell() == 2 and torch.equal(sparse[11]["D"], D[11])
+    a = DeviceBatchLoader(dense, 32, shuffle=True, seed=5, count_dtype=None, sparse_dosage=False)  # as the reference stores it
+    b = DeviceBatchLoader(sparse, 32, shuffle=True, seed=5)
+    assert b.stored_bytes() < 0.5 * a.stored_bytes()
+    for x, y in zip(a, b):
+        assert set(x) == set(y)
+        for k in x:
+            assert x[k].dtype == y[k].dtype and torch.equal(x[k], y[k]), k
+    # the in-memory data module keeps D sparse throughout
+    names = ["ctl" if not r.any() else "+".join(f"g{j}" for j in torch.nonzero(r).squeeze(1).tolist()) for r in D]
+    splits = np.where(np.arange(n) % 5 == 0, "val", np.where(np.arange(n) % 7 == 0, "test", "train"))
+    dm = TensorPerturbationDataModule(X, sp, qc, names, splits, batch_size=16, control_label="ctl")
+    assert isinstance(dm.D, SparseDosage) and isinstance(dm.datasets["train"].D, SparseDosage)
+    tr = splits == "train"
+    assert torch.equal(dm.get_train_perturbation_obs_counts(), (D[tr] != 0).sum(0))
+    bt = next(iter(dm.train_dataloader()))
+    assert bt["D"].shape == (16, T) and torch.equal(bt["D"], D[torch.from_numpy(np.nonzero(tr)[0])][
+        torch.tensor([list(dm.datasets["train"].ids).index(f"cell{int(i)}") for i in
+                      torch.from_numpy(np.nonzero(tr)[0])[bt["idx"]]])])
+    some = dm.get_unique_observed_intervention_info().index[:3]
+    assert dm.get_unique_observed_intervention_dosages(some).shape == (3, T)
+
+
 def test_compat_alias_package_resolves_reference_import_paths():
     """`import cradle_vae...` with <repo>/compat on the path lands on this build (run in a child
     process so that the alias never shadows the reference for the golden-fixture tooling)."""
@@ -204,7 +255,7 @@ def test_synthetic_data_module_interface():
     dm = SyntheticPerturbationDataModule(n_cells=500, n_genes=24, n_guides=4, batch_size=50, seed=3)
     n_tr = len(dm.datasets["train"])
     assert n_tr + len(dm.datasets["val"]) + len(dm.datasets["test"]) == 500
-    assert torch.equal(dm.get_train_perturbation_obs_counts(), (dm.datasets["train"].D != 0).sum(0))
+    assert torch.equal(dm.get_train_perturbation_obs_counts(), (dm.datasets["train"].D.dense() != 0).sum(0))
     assert dm.get_qc_n()["n_qc_pass"] + dm.get_qc_n()["n_qc_fail"] == 500
     stats = dm.get_x_train_statistics()
     assert stats.log_x_mean.shape == (24,) and bool((stats.log_x_std > 0).all())
