@@ -232,7 +232,8 @@ def _plain_config(config: Dict) -> Dict:
     import copy
     import dataclasses
 
-    cfg = copy.copy(config)
+    # plain dicts only (preprocess_config hands out a defaultdict, which a weights_only load refuses)
+    cfg = {k: (dict(v) if isinstance(v, dict) else copy.copy(v)) for k, v in config.items()}
     gk = dict(cfg.get("guide_kwargs", {}))
     stats = gk.get("x_normalization_stats")
     if dataclasses.is_dataclass(stats):

@@ -199,6 +199,33 @@ def test_sparse_dosage_and_packed_counts_give_the_dense_loaders_batches():
     assert dm.get_unique_observed_intervention_dosages(some).shape == (3, T)
 
 
+def test_config_semantics_match_the_reference_on_its_demo_yamls():
+    """preprocess_config / add_data_info_to_config against the outputs of the reference's own functions
+    (train_norman.py:163-227, run by oracle/make_config_golden.py) on its four demo yamls plus a case with the rules
+    the demo files do not use: 'a--b' shared keys, shared n_latent, gradient_clip_norm -1, dots beyond one level."""
+    import json
+    import os
+
+    from cradle_vae_amd.config import add_data_info_to_config, load_config, preprocess_config
+    from oracle.make_config_golden import FakeDataModule
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = json.load(open(os.path.join(root, "tests", "golden", "config_demo.json")))
+    assert len(cases) == 5
+    for name, c in cases.items():
+        got = preprocess_config(dict(c["input"]))
+        assert json.loads(json.dumps(got)) == c["processed"], name
+        if "with_data_info" in c:
+            full = add_data_info_to_config(preprocess_config(dict(c["input"])), FakeDataModule())
+            assert json.loads(json.dumps(full)) == c["with_data_info"], name
+    rules = cases["synthetic_rules"]["processed"]
+    assert rules["gradient_clip_norm"] is None and rules["model_kwargs"] == {"n_latent": 7, "x": 3} and rules["g"] == {"h.i": 1}
+    # this build's own demo file goes through the same functions
+    cfg = preprocess_config(load_config(os.path.join(root, "demo", "cradle_vae_synthetic.yaml")))
+    assert cfg["model_kwargs"]["n_latent"] == cfg["guide_kwargs"]["n_latent"] == 32
+    assert cfg["data_module"] == "SyntheticPerturbationDataModule" and cfg["data_module_kwargs"]["batch_size"] == 256
+
+
 def test_compat_alias_package_resolves_reference_import_paths():
     """`import cradle_vae...` with <repo>/compat on the path lands on this build (run in a child
     process so that the alias never shadows the reference for the golden-fixture tooling)."""
