@@ -68,6 +68,15 @@ PROTOTYPES = {
          ctypes.c_float, ctypes.c_float, i32, ctypes.c_float, ctypes.c_float, c_float_p, ctypes.c_void_p, c_stream],
     ),
     "cradle_adam_workspace_floats": (i64, []),
+    "cradle_grad_region_sumsq": (i32, [c_float_p, ctypes.POINTER(i64), ctypes.POINTER(i64), i32, i32, c_float_p, c_float_p,
+                                       c_stream]),
+    "cradle_adam_regions_workspace_floats": (i64, []),
+    "cradle_adam_step_regions": (
+        i32,
+        [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.POINTER(i64), ctypes.POINTER(i64), i32, c_float_p, i32,
+         ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, i32, ctypes.c_float,
+         ctypes.c_float, c_float_p, ctypes.c_void_p, c_stream],
+    ),
     "cradle_nb_sample_accumulate_ws": (
         i32,
         [c_float_p, i64, c_float_p, i32, c_float_p, c_float_p, c_float_p, i32, i32, i32, i32, i32, ctypes.c_uint64,

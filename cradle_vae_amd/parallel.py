@@ -62,6 +62,55 @@ def _all_reduce(t: torch.Tensor, op=None) -> None:
         dist.all_reduce(t, **kw)
 
 
+def group_size() -> int:
+    dist = torch.distributed
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def reduce_scatter_inplace_(bucket: torch.Tensor, rank: int, world: int) -> None:
+    """Sum of ``bucket`` (a contiguous 1-D view, length divisible by ``world``) over ranks, delivered into this rank's
+    piece ``bucket[rank * n/world : (rank + 1) * n/world]`` -- RCCL's in-place reduce-scatter.  gloo has no
+    reduce-scatter: there the whole bucket is all-reduced through host memory (rehearsals and tests; same sums)."""
+    dist = torch.distributed
+    if world == 1 and not (dist.is_initialized() and dist.get_backend() == "nccl"):
+        return  # (a one-rank RCCL group still makes the call: tests exercise the library's stream ordering with it)
+    n = bucket.numel() // world
+    if dist.get_backend() == "gloo":
+        _all_reduce(bucket)
+        return
+    dist.reduce_scatter_tensor(bucket[rank * n:(rank + 1) * n], bucket)
+
+
+def all_gather_inplace_(bucket: torch.Tensor, rank: int, world: int) -> None:
+    """Every rank's piece of ``bucket`` (as in reduce_scatter_inplace_) to all ranks, in place."""
+    dist = torch.distributed
+    if world == 1 and not (dist.is_initialized() and dist.get_backend() == "nccl"):
+        return
+    n = bucket.numel() // world
+    if dist.get_backend() == "gloo":
+        mine = bucket[rank * n:(rank + 1) * n].detach().cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        bucket.copy_(torch.cat(parts))
+        return
+    dist.all_gather_into_tensor(bucket, bucket[rank * n:(rank + 1) * n])
+
+
+def all_gather_small(mine: torch.Tensor, world: int) -> torch.Tensor:
+    """(k,) per rank -> (world * k,), rank-major."""
+    dist = torch.distributed
+    if world == 1:
+        return mine.clone()
+    if dist.get_backend() == "gloo":
+        h = mine.detach().cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h)
+        return torch.cat(parts).to(mine.device)
+    out = torch.empty(world * mine.numel(), device=mine.device, dtype=mine.dtype)
+    dist.all_gather_into_tensor(out, mine)
+    return out
+
+
 def allreduce_mean_grads_(params: List[torch.nn.Parameter], world_size: int) -> None:
     """Averages ``p.grad`` over ranks through one flat bucket (modular path)."""
     if world_size == 1:

@@ -47,12 +47,66 @@ class TrainStep:
             self.exp_avg = torch.zeros_like(a.flat)
             self.exp_avg_sq = torch.zeros_like(a.flat)
             self.norm_ws = torch.zeros(hip.load().cradle_adam_workspace_floats(), device=self.device)
-            # N > 1: bucketed gradient all-reduce overlapped with the backward pass (CRADLE_OVERLAP_ALLREDUCE=0
-            # falls back to one all-reduce of the whole arena after the step)
+            # N > 1: gradients are synchronised in four buckets, in the order the backward pass finishes them, on a
+            # communication stream that runs under the remaining backward kernels.  Two forms (CRADLE_GRAD_SYNC):
+            #   "rs_ag" (default): reduce-scatter every bucket, clip + Adam on this rank's 1/N of each bucket only,
+            #           all-gather the updated parameters -- the same bytes on the wire as an all-reduce, 1/N of the
+            #           optimiser's HBM traffic, and collectives RCCL can run as direct exchanges over the xGMI mesh;
+            #   "allreduce": all-reduce every bucket, full update on every rank (the reference's DDP semantics as
+            #           they are usually implemented).  CRADLE_OVERLAP_ALLREDUCE=0: one all-reduce after the step.
+            # All three give bit-identical parameters (tests/test_ddp_gpu.py).
             self.overlap = world_size > 1 and os.environ.get("CRADLE_OVERLAP_ALLREDUCE", "1") != "0"
+            self.group_world = parallel.group_size() if world_size > 1 else 1
+            self.group_rank = torch.distributed.get_rank() if self.group_world > 1 else 0
+            shardable = 64 % (4 * self.group_world) == 0  # arena segments are multiples of 64 floats
+            self.grad_sync = os.environ.get("CRADLE_GRAD_SYNC", "rs_ag" if shardable else "allreduce")
+            if self.grad_sync == "rs_ag" and (not shardable or not self.overlap):
+                self.grad_sync = "allreduce"
+            if world_size > 1:
+                self._setup_regions(a, shardable)
             if self.overlap:
                 self.fused.bucket_events = (hip.EventPair(), hip.EventPair())
                 self.comm_stream = torch.cuda.Stream(device=self.device)
+
+    def _setup_regions(self, a, shardable):
+        """Buckets in backward-completion order and their per-rank pieces; region index = rank * 4 + bucket."""
+        import ctypes
+
+        from . import hip
+
+        o_enc, o_dec, o_out = a.offsets["enc.W0"], a.offsets["dec.W0"], a.offsets["dec.Wh"]
+        self.buckets = [(o_out, a.numel), (o_dec, o_out), (o_enc, o_dec), (0, o_enc)]
+        gw = self.group_world if shardable else 1
+        self.piece_world = gw
+        pieces = [[(s + r * ((e - s) // gw), (e - s) // gw) for (s, e) in self.buckets] for r in range(gw)]
+        flat = [pc for rank_pieces in pieces for pc in rank_pieces]
+        arr = lambda vals: (ctypes.c_int64 * len(vals))(*vals)
+        self._all_regions = (arr([o for o, _ in flat]), arr([n for _, n in flat]), len(flat))
+        mine = pieces[self.group_rank if shardable else 0]
+        self._my_regions = (arr([o for o, _ in mine]), arr([n for _, n in mine]), len(mine))
+        lib = hip.load()
+        self.region_ws = torch.zeros(lib.cradle_adam_regions_workspace_floats(), device=self.device)
+        self.region_sums = torch.zeros(len(flat), device=self.device)
+        self.norm_out = torch.zeros(1, device=self.device)
+
+    def _adam_regions(self, a, regions, all_sums):
+        from . import hip
+
+        off, ln, n = regions
+        hip.check(
+            hip.load().cradle_adam_step_regions(
+                a.flat.data_ptr(), a.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), off, ln, n,
+                all_sums.data_ptr(), all_sums.numel(), self.lr, 0.9, 0.999, 1e-8, self.weight_decay, self.step_count,
+                float(self.clip) if self.clip is not None else -1.0, 1.0 / self.world_size, self.norm_out.data_ptr(),
+                self.fused.flags.data_ptr(), hip.stream()),
+            "cradle_adam_step_regions")
+
+    def _region_sumsq(self, a, regions, out):
+        from . import hip
+
+        off, ln, n = regions
+        hip.check(hip.load().cradle_grad_region_sumsq(a.grad.data_ptr(), off, ln, n, self._all_regions[2], out.data_ptr(),
+                                                      self.region_ws.data_ptr(), hip.stream()), "cradle_grad_region_sumsq")
 
     def draw_noise(self, P, N):
         g = self.lm.guide
@@ -72,11 +126,11 @@ class TrainStep:
             n_particles=n_particles, **({"gen_plated": self.gen_plated, "gen_local": self.gen_local}
                                          if self.rng == "torch" else {}))
         a = f.arena
-        if self.world_size > 1 and self.overlap:
-            self._bucketed_allreduce(a)
-        else:
-            parallel.allreduce_sum_(a.grad, self.world_size)  # one RCCL call on the flat gradient arena; averaged inside Adam
         self.step_count += 1
+        if self.world_size > 1:
+            self._sync_and_update(a)
+            self.last_out = out
+            return out[0]
         hip.check(
             hip.load().cradle_adam_step(
                 a.flat.data_ptr(), a.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), a.numel,
@@ -87,28 +141,44 @@ class TrainStep:
         self.last_out = out
         return out[0]
 
-    def _bucketed_allreduce(self, a):
-        """Sum of the gradient arena over ranks in four contiguous buckets, in the order the backward
-        pass finishes them (decoder output layer, rest of the decoder, basal encoder, the rest), on a
-        communication stream that waits for the events the step records: the first three all-reduces
-        run under the remaining backward kernels."""
+    def _sync_and_update(self, a):
+        """Gradient synchronisation + clip + Adam for more than one rank (see __init__ for the three forms)."""
         from . import hip
 
-        lib = hip.load()
-        ev = self.fused.bucket_events
-        o_enc, o_dec, o_out = a.offsets["enc.W0"], a.offsets["dec.W0"], a.offsets["dec.Wh"]
-        cur = torch.cuda.current_stream()
-        with torch.cuda.stream(self.comm_stream):
-            cs = self.comm_stream.cuda_stream
-            hip.check(lib.cradle_stream_wait_event(cs, ev[0].begin), "stream_wait_event")
-            parallel._all_reduce(a.grad[o_out:])  # decoder output layer + log_c: a third of the arena, final first
-            hip.check(lib.cradle_stream_wait_event(cs, ev[0].end), "stream_wait_event")
-            parallel._all_reduce(a.grad[o_dec:o_out])
-            hip.check(lib.cradle_stream_wait_event(cs, ev[1].begin), "stream_wait_event")
-            parallel._all_reduce(a.grad[o_enc:o_dec])
-            self.comm_stream.wait_stream(cur)  # q(M), q(E|M), q(qc_E): final when the step is
-            parallel._all_reduce(a.grad[:o_enc])
-        cur.wait_stream(self.comm_stream)
+        gw, rk = self.piece_world, self.group_rank
+        shard = self.grad_sync == "rs_ag"
+        if not self.overlap:
+            parallel.allreduce_sum_(a.grad, self.world_size)  # one RCCL call on the flat gradient arena
+        else:
+            # buckets in the order the backward pass finishes them (decoder output layer, rest of the decoder, basal
+            # encoder, the rest), each as soon as the event the step recorded for it has fired
+            lib = hip.load()
+            ev = self.fused.bucket_events
+            waits = (ev[0].begin, ev[0].end, ev[1].begin, None)
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(self.comm_stream):
+                cs = self.comm_stream.cuda_stream
+                for (s, e), w in zip(self.buckets, waits):
+                    if w is not None:
+                        hip.check(lib.cradle_stream_wait_event(cs, w), "stream_wait_event")
+                    else:
+                        self.comm_stream.wait_stream(cur)  # q(M), q(E|M), q(qc_E): final when the step is
+                    if shard:
+                        parallel.reduce_scatter_inplace_(a.grad[s:e], rk, gw)
+                    else:
+                        parallel._all_reduce(a.grad[s:e])
+            cur.wait_stream(self.comm_stream)
+        # |g|^2 = in-order sum of the region sums (bucket x rank), whoever computes them
+        if shard:
+            mine = self.region_sums[:self._my_regions[2]]
+            self._region_sumsq(a, self._my_regions, mine)
+            all_sums = parallel.all_gather_small(mine, gw)
+            self._adam_regions(a, self._my_regions, all_sums)
+            for (s, e) in self.buckets:
+                parallel.all_gather_inplace_(a.flat[s:e], rk, gw)
+        else:
+            self._region_sumsq(a, self._all_regions, self.region_sums)
+            self._adam_regions(a, self._all_regions, self.region_sums)
 
     def __call__(self, batch: Dict[str, torch.Tensor], n_particles: int) -> torch.Tensor:
         if self.fused is not None:

@@ -264,6 +264,23 @@ int cradle_adam_step(float* params, const float* grads, float* exp_avg, float* e
                      float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
                      float grad_scale, float* norm_ws, const int* skip_flags, cradle_stream_t stream);
 int64_t cradle_adam_workspace_floats(void);
+/* The same update with the optimiser work sharded over data-parallel ranks (what Lightning's ddp strategy leaves to
+ * every rank in full, train_norman.py:89-97).  The arena is cut into n_total regions (gradient bucket x rank; offsets and
+ * lengths in floats, host arrays, offsets multiples of 4).  |g|^2 is defined as the in-order sum of per-region sums, each
+ * computed the same way by whoever computes it, so that reduce-scatter + sharded update + all-gather and all-reduce +
+ * full update give bit-identical parameters.
+ *   cradle_grad_region_sumsq : region_sums[i] = sum_{region i} grads^2 for the n_regions listed regions (ws:
+ *                              cradle_adam_regions_workspace_floats() floats)
+ *   cradle_adam_step_regions : clip + Adam on the listed regions only; all_sums (device, n_sums = n_total) = the region
+ *                              sums of the whole arena (all-gathered over ranks); norm_out (may be NULL) receives |g'| */
+int cradle_grad_region_sumsq(const float* grads, const int64_t* region_off, const int64_t* region_len, int n_regions,
+                             int n_total, float* region_sums, float* ws, cradle_stream_t stream);
+int64_t cradle_adam_regions_workspace_floats(void);
+int cradle_adam_step_regions(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                             const int64_t* region_off, const int64_t* region_len, int n_regions, const float* all_sums,
+                             int n_sums, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                             float max_norm, float grad_scale, float* norm_out, const int* skip_flags,
+                             cradle_stream_t stream);
 
 /* ---- K9: Gamma-Poisson observation sampler fused with the ATE accumulation ---------------
  * Replaces, per (particle p, condition t) row r = p*C + t of decoder logits:

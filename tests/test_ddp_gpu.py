@@ -20,9 +20,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, port, overlap, out):
+def _worker(rank, port, overlap, out, sync="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo",
-                      CRADLE_OVERLAP_ALLREDUCE="1" if overlap else "0")
+                      CRADLE_OVERLAP_ALLREDUCE="1" if overlap else "0", CRADLE_GRAD_SYNC=sync)
     import torch.distributed as dist
 
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
@@ -36,7 +36,7 @@ def _worker(rank, port, overlap, out):
         case = gio.load_elbo("mid", torch.float32, "cuda:0")
         lm = build_loss_module(case)
         st = TrainStep(lm, lr=1e-3, world_size=WORLD, seed=7)
-        assert st.fused is not None and st.overlap == overlap
+        assert st.fused is not None and st.overlap == overlap and st.grad_sync == sync
         shape = syn.MID
         batch = syn.make_batch(shape, seed=50 + rank, device="cuda:0")  # each rank its own cells
         losses = [float(st(batch, n_particles=shape.n_particles)) for _ in range(4)]
@@ -46,12 +46,12 @@ def _worker(rank, port, overlap, out):
         dist.destroy_process_group()
 
 
-def _run(overlap):
+def _run(overlap, sync="allreduce"):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         out = mgr.dict()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, port, overlap, out)) for r in range(WORLD)]
+        procs = [ctx.Process(target=_worker, args=(r, port, overlap, out, sync)) for r in range(WORLD)]
         for p in procs:
             p.start()
         for p in procs:
@@ -70,13 +70,19 @@ def test_overlapped_bucket_allreduce_equals_single_allreduce():
     assert torch.equal(b[0][0], b[1][0]), "ranks diverged with the single all-reduce"
     assert torch.equal(a[0][0], b[0][0]), "bucketed and single all-reduce disagree"
     assert a[0][1] != a[1][1]  # different cells per rank: different local losses
+    # reduce-scatter + clip/Adam on each rank's half of every bucket + all-gather of the parameters
+    c = _run(overlap=True, sync="rs_ag")
+    assert torch.equal(c[0][0], c[1][0]), "ranks diverged with reduce-scatter / sharded Adam / all-gather"
+    assert torch.equal(c[0][0], a[0][0]), "sharded and full optimiser updates disagree"
+    assert c[0][1] == a[0][1]
 
 
-def _rccl_worker(port, overlap, out):
+def _rccl_worker(port, overlap, out, sync="allreduce"):
     """One rank, backend nccl (= RCCL): the data-parallel step exactly as bench.py --gpus N runs it,
     on the only GPU a test box has.  world_size 2 is what TrainStep is told, so the bucket events, the
     communication stream and RCCL's own stream ordering are all exercised; the group itself has one rank."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CRADLE_OVERLAP_ALLREDUCE="1" if overlap else "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CRADLE_OVERLAP_ALLREDUCE="1" if overlap else "0",
+                      CRADLE_GRAD_SYNC=sync)
     import torch.distributed as dist
 
     torch.cuda.set_device(0)
@@ -93,12 +99,12 @@ def _rccl_worker(port, overlap, out):
 
         lm = build_loss_module(gio.load_elbo("mid", torch.float32, "cuda:0"))
         st = TrainStep(lm, lr=1e-3, world_size=2, seed=7)  # grads are halved in Adam either way
-        assert st.fused is not None and st.overlap == overlap
+        assert st.fused is not None and st.overlap == overlap and st.grad_sync == sync
         batch = syn.make_batch(syn.MID, seed=50, device="cuda:0")
         losses = [float(st(batch, n_particles=syn.MID.n_particles)) for _ in range(4)]
         dist.barrier()
         torch.cuda.synchronize()
-        out[int(overlap)] = (st.fused.arena.flat.detach().cpu().clone(), losses)
+        out[(int(overlap), sync)] = (st.fused.arena.flat.detach().cpu().clone(), losses)
     finally:
         dist.destroy_process_group()
 
@@ -107,17 +113,18 @@ def test_rccl_backend_bucketed_allreduce_single_rank():
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         out = mgr.dict()
-        for overlap in (True, False):
-            p = ctx.Process(target=_rccl_worker, args=(_free_port(), overlap, out))
+        for overlap, sync in ((True, "allreduce"), (False, "allreduce"), (True, "rs_ag")):
+            p = ctx.Process(target=_rccl_worker, args=(_free_port(), overlap, out, sync))
             p.start()
             p.join(timeout=150)
             if p.is_alive():
                 p.kill()
             if "skip" in out:
                 pytest.skip("RCCL process group could not be created here: " + out["skip"])
-            assert p.exitcode == 0, f"RCCL worker (overlap={overlap}) failed"
-        a, b = out[1], out[0]
+            assert p.exitcode == 0, f"RCCL worker (overlap={overlap}, {sync}) failed"
+        a, b, c = out[(1, "allreduce")], out[(0, "allreduce")], out[(1, "rs_ag")]
     assert torch.equal(a[0], b[0]) and a[1] == b[1], "bucketed and single RCCL all-reduce disagree"
+    assert torch.equal(a[0], c[0]) and a[1] == c[1], "RCCL reduce-scatter / all-gather form disagrees"
     assert all(x == x for x in a[1])
 
 
