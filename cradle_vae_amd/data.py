@@ -278,7 +278,8 @@ def batch_log_std(X: torch.Tensor, log_mean: torch.Tensor, correction: int = 1, 
 def build_counterfactual_inputs(X: torch.Tensor, treatment_codes: torch.Tensor, qc_fail: torch.Tensor,
                                 n_peers: int = 50, generator: Optional[torch.Generator] = None,
                                 peer_index: Optional[Dict[int, torch.Tensor]] = None,
-                                max_rows_per_gather: int = 1 << 22) -> torch.Tensor:
+                                max_rows_per_gather: int = 1 << 22,
+                                reference_source: Optional[torch.Tensor] = None) -> torch.Tensor:
     """cfX of one split (reference ``_get_cfX``, cradle_vae/data/norman/data_module.py:175-191): for every
     cell, the per-gene (lower) median over ``min(n_peers, #fail)`` QC-failing cells of the same treatment,
     drawn with replacement; zeros when the treatment has no QC-failing cell.  Runs on X's device, one
@@ -286,12 +287,21 @@ def build_counterfactual_inputs(X: torch.Tensor, treatment_codes: torch.Tensor, 
 
     ``peer_index`` ({treatment code: (n_cells_of_t, k) positions into that treatment's fail list}) injects
     the draws (tests); otherwise they come from ``generator``.
+
+    ``reference_source``: the reference groups the split's QC-failing cells with ``groupby("treatment").indices``
+    -- positions within that *filtered* frame -- and then indexes the un-split count matrix of the whole data set
+    with them (:177-190: ``X`` is the full matrix there).  The rows whose median it takes are therefore
+    ``X_all[j]`` for ``j`` = the peer's rank among the split's QC-failing cells, not the peer's own counts.  Passing
+    the whole data set's matrix here reproduces exactly that (pinned by tests/golden/cfx_tiny.npz, the output of
+    the reference's own function); without it the peers' own rows are used -- what the procedure means to do.
     """
     dev = X.device
     n, G = X.shape
     cfX = torch.zeros((n, G), device=dev, dtype=X.dtype)
     codes = treatment_codes.to(dev)
     fail = qc_fail.to(dev).bool()
+    source = X if reference_source is None else reference_source.to(dev)
+    rank_among_fails = torch.cumsum(fail.long(), 0) - 1  # position of a failing cell within the split's failing cells
     for t in torch.unique(codes).tolist():
         members = torch.nonzero(codes == t).squeeze(1)
         fails = torch.nonzero((codes == t) & fail).squeeze(1)
@@ -304,8 +314,10 @@ def build_counterfactual_inputs(X: torch.Tensor, treatment_codes: torch.Tensor, 
             pos = torch.randint(0, fails.numel(), (members.numel(), k), device=dev, generator=generator)
         rows_per = max(1, max_rows_per_gather // (k * G))
         for s in range(0, members.numel(), rows_per):
-            sel = fails[pos[s:s + rows_per]]  # (m, k) global row indices
-            cfX[members[s:s + rows_per]] = X[sel].median(dim=1)[0]
+            sel = fails[pos[s:s + rows_per]]  # (m, k) rows of the split
+            if reference_source is not None:
+                sel = rank_among_fails[sel]  # the reference's positions, read from the un-split matrix
+            cfX[members[s:s + rows_per]] = source[sel].median(dim=1)[0].to(cfX.dtype)
     return cfX
 
 
@@ -320,7 +332,11 @@ class TensorPerturbationDataModule:
     def __init__(self, X: torch.Tensor, D: torch.Tensor, qc: torch.Tensor, treatments: Iterable[str], splits: Iterable[str],
                  x_var_names: Optional[Iterable[str]] = None, d_var_names: Optional[Iterable[str]] = None,
                  qc_var_names: Optional[Iterable[str]] = None, batch_size: int = 512, device=None, seed: int = 0,
-                 control_label: Optional[str] = None, rank: int = 0, world_size: int = 1):
+                 control_label: Optional[str] = None, rank: int = 0, world_size: int = 1,
+                 cf_indexing: str = "reference"):
+        """``cf_indexing="reference"`` builds cfX exactly as the reference's ``_get_cfX`` does, peers' rows read from
+        the un-split matrix by their rank among the split's QC-failing cells (see build_counterfactual_inputs);
+        ``"same_treatment"`` takes the median over the peers' own counts."""
         import pandas as pd
 
         self.device = torch.device(device) if device is not None else X.device
@@ -348,7 +364,8 @@ class TensorPerturbationDataModule:
             idx = torch.from_numpy(np.nonzero((self.obs["split"] == split).to_numpy())[0])
             di = idx.to(self.device)
             Xs = self.X[di]
-            cfX = build_counterfactual_inputs(Xs, codes[idx], self.qc[di].max(dim=1)[0] != 0, generator=gen)
+            cfX = build_counterfactual_inputs(Xs, codes[idx], self.qc[di].max(dim=1)[0] != 0, generator=gen,
+                                              reference_source=self.X if cf_indexing == "reference" else None)
             self.datasets[split] = SCRNASeqTensorPerturbationDataset(Xs, self.D.rows(di), self.qc[di], cfX, ids=ids[idx.numpy()])
         Xtr = self.datasets["train"].X
         log_mean = batch_log_mean(Xtr)

@@ -276,6 +276,42 @@ def test_counterfactual_builder_matches_per_cell_loop():
     assert torch.equal(got, want) and float(got[codes == 3].abs().sum()) == 0.0
 
 
+def test_counterfactual_builder_matches_the_references_own_output():
+    """build_counterfactual_inputs against the output of the reference's ``_get_cfX`` itself
+    (norman/data_module.py:175-191, executed by oracle/make_cfx_golden.py with its np.random.choice draws recorded):
+    same draws in, same cfX out, for all three splits -- including the reference's indexing of the un-split matrix
+    with positions taken inside the split's QC-failing subset."""
+    import os
+
+    from cradle_vae_amd.data import build_counterfactual_inputs
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfx_tiny.npz"), allow_pickle=False)
+    X_all = torch.from_numpy(z["X"])
+    treatment, split, qc = z["treatment"], z["split"], z["total_qc"]
+    for sp in ("train", "val", "test"):
+        rows = np.nonzero(split == sp)[0]
+        codes, fail = torch.from_numpy(treatment[rows]), torch.from_numpy(qc[rows] == 1)
+        draws = z[f"draws/{sp}"]  # per cell: positions (within the split's failing cells) np.random.choice returned
+        fail_rank_to_row = np.nonzero(fail.numpy())[0]
+        peers = {}
+        for t in np.unique(treatment[rows]):
+            members = np.nonzero(codes.numpy() == t)[0]
+            fails_t = np.nonzero((codes.numpy() == t) & fail.numpy())[0]
+            if len(fails_t) == 0:
+                assert (draws[members] == -1).all()
+                continue
+            k = min(50, len(fails_t))
+            assert (draws[members, :k] >= 0).all() and (draws[members, k:] == -1).all()
+            # drawn value = rank among the split's failing cells -> that cell's position in its treatment's fail list
+            rows_drawn = fail_rank_to_row[draws[members, :k]]
+            assert np.isin(rows_drawn, fails_t).all()  # the reference draws peers of the same treatment ...
+            peers[int(t)] = torch.from_numpy(np.searchsorted(fails_t, rows_drawn))
+        got = build_counterfactual_inputs(X_all[rows], codes, fail, peer_index=peers, reference_source=X_all)
+        assert torch.equal(got, torch.from_numpy(z[f"cfX/{sp}"])), sp
+        meant = build_counterfactual_inputs(X_all[rows], codes, fail, peer_index=peers)
+        assert not torch.equal(meant, got)  # ... but reads other cells' counts than theirs
+
+
 def test_synthetic_data_module_interface():
     from cradle_vae_amd.data import SyntheticPerturbationDataModule
 
