@@ -377,3 +377,96 @@ def test_max_dosages_per_cell_reaches_the_loss_module():
     finally:
         trainer.TrainStep = orig
     assert seen["kmax"] == 3
+
+
+def _layout():
+    import json
+
+    with open(os.path.join(gio.GOLDEN, "lightning_layout.json")) as f:
+        return json.load(f)
+
+
+def reference_checkpoint_case(device="cpu"):
+    """The state dict the reference's own TrainConfigPerturbationLightningModule accepted (strict) and the ELBO it
+    computed from it, with its config (oracle/make_checkpoint_golden.py)."""
+    from cradle_vae_amd.guide import ObservationNormalizationStatistics
+
+    z = np.load(os.path.join(gio.GOLDEN, "lightning_layout.npz"), allow_pickle=False)
+    lay = _layout()["small_values"]
+    config = lay["config"]
+    config["guide_kwargs"]["x_normalization_stats"] = ObservationNormalizationStatistics(
+        log_x_mean=torch.from_numpy(z["log_x_mean"]), log_x_std=torch.from_numpy(z["log_x_std"]))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    # Lightning writes the predictor's aliases of the same tensors too
+    for key, _, _ in lay["state_dict"]:
+        if key.startswith("predictor."):
+            sd[key] = sd["loss_module." + key[len("predictor."):]]
+    sd = {key: sd[key] for key, _, _ in lay["state_dict"]}
+    grp = lambda p: {k[len(p) + 1:]: torch.from_numpy(z[k]).to(device) for k in z.files if k.startswith(p + "/")}
+    return dict(config=config, state_dict=sd, batch=grp("batch"), noise=grp("noise"), cf_noise=grp("cf_noise"),
+                loss=float(z["loss"]), metrics={k: float(v) for k, v in grp("metrics").items()},
+                n_particles=int(z["n_particles"]))
+
+
+@pytest.mark.parametrize("yaml_name", ["cradle_vae_norman.yaml", "cradle_vae_replogle.yaml", "cradle_vae_adamson.yaml",
+                                       "cradle_vae_dixit.yaml"])
+def test_state_dict_layout_equals_the_reference_modules(yaml_name):
+    """Key order, shapes and dtypes of state_dict(), the optimizer and pos_weight of the module built from the
+    reference's demo yaml equal those of the reference's own module built from the same config (fixture)."""
+    from cradle_vae_amd.config import add_data_info_to_config, preprocess_config
+    from cradle_vae_amd.guide import ObservationNormalizationStatistics
+    from cradle_vae_amd.models.utils.perturbation_lightning_module import TrainConfigPerturbationLightningModule
+    import json
+
+    with open(os.path.join(gio.GOLDEN, "config_demo.json")) as f:
+        raw = json.load(f)[yaml_name]["input"]
+    lay = _layout()[yaml_name]
+    T = [s for k, s, _ in lay["state_dict"] if k == "D_obs_counts_train"][0][0]
+    G = [s for k, s, _ in lay["state_dict"] if k == "loss_module.model.decoder.log_concentration"][0][0]
+
+    class DM:
+        class _F:
+            def __init__(self, n):
+                self.shape = (n, 0)
+
+        def get_d_var_info(self):
+            return self._F(T)
+
+        def get_x_var_info(self):
+            return self._F(G)
+
+        def get_qc_var_info(self):
+            return self._F(1)
+
+        def get_x_train_statistics(self):
+            return ObservationNormalizationStatistics(log_x_mean=torch.zeros(G), log_x_std=torch.ones(G))
+
+        def get_qc_n(self):
+            return {"n_qc_pass": 900, "n_qc_fail": 100}
+
+    config = add_data_info_to_config(preprocess_config(dict(raw)), DM())
+    mod = TrainConfigPerturbationLightningModule(config=config)
+    mine = [[k, list(v.shape), str(v.dtype)] for k, v in mod.state_dict().items()]
+    assert mine == lay["state_dict"]
+    assert sum(p.numel() for p in mod.parameters()) == lay["n_parameters"]
+    opt = mod.configure_optimizers()
+    o = lay["optimizer"]
+    assert type(opt).__name__ == o["cls"] and opt.defaults["lr"] == o["lr"] and opt.defaults["eps"] == o["eps"]
+    assert opt.defaults["weight_decay"] == o["weight_decay"] and list(opt.defaults["betas"]) == o["betas"]
+    assert sum(len(g["params"]) for g in opt.param_groups) == o["n_param_tensors"]
+    assert mod.loss_module.pos_weight == lay["pos_weight"] and mod.n_particles == lay["n_particles"]
+
+
+def test_checkpoint_in_the_references_layout_loads_strictly(tmp_path):
+    """A file shaped like Lightning's checkpoint of the reference module ({"state_dict", "hyper_parameters"}) with the
+    reference's own key set loads with strict=True and gives back every tensor."""
+    from cradle_vae_amd.lightning_module import load_checkpoint
+    from cradle_vae_amd.models.utils.perturbation_lightning_module import TrainConfigPerturbationLightningModule
+
+    case = reference_checkpoint_case()
+    mod = TrainConfigPerturbationLightningModule(config=case["config"])
+    missing, unexpected = mod.load_state_dict(case["state_dict"], strict=True)
+    assert not missing and not unexpected
+    for k, v in mod.state_dict().items():
+        assert torch.equal(v, case["state_dict"][k]), k
+    assert mod.predictor.guide is mod.loss_module.guide and mod.predictor.model is mod.loss_module.model

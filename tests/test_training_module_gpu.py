@@ -144,3 +144,25 @@ def test_train_and_eval_entry_points_from_a_yaml(tmp_path):
                          "--qc_pass", "false"])
     assert np.isfinite(m["test/IWELBO"]) and "pearsonr-all" in m or any(k.endswith("-all") for k in m)
     assert (rdir / "test_metrics.csv").exists()
+
+
+def test_module_loaded_from_a_reference_layout_checkpoint_gives_the_references_loss():
+    """The state dict the reference's own Lightning module accepted, loaded here, gives the ELBO and the loss terms
+    the reference computed from it on the same batch and noise (fixture: oracle/make_checkpoint_golden.py)."""
+    from cradle_vae_amd.models.utils.perturbation_lightning_module import TrainConfigPerturbationLightningModule
+    from tests.test_host_logic_cpu import reference_checkpoint_case
+
+    case = reference_checkpoint_case(device="cuda")
+    mod = TrainConfigPerturbationLightningModule(config=case["config"])
+    mod.load_state_dict(case["state_dict"], strict=True)
+    mod = mod.to("cuda")
+    b = case["batch"]
+    for impl in ("fused", "modular"):
+        mod.loss_module.step = impl
+        loss, metrics = mod.loss_module.loss(
+            X=b["X"], D=b["D"], D_obs_counts=mod.D_obs_counts_train, qc=b["qc"], qc_obs_counts=mod.qc_obs_counts_train,
+            cfX=b["cfX"], condition_values={"library_size": b["library_size"]}, n_particles=case["n_particles"],
+            noise=case["noise"], cf_noise=case["cf_noise"])
+        assert abs(float(loss) - case["loss"]) <= 1e-4 * abs(case["loss"]), (impl, float(loss), case["loss"])
+        for k, v in case["metrics"].items():
+            assert abs(float(metrics[k]) - v) <= 1e-4 * max(abs(v), 1e-3), (impl, k, float(metrics[k]), v)
