@@ -18,7 +18,7 @@ from oracle import ref_harness as rh  # noqa: E402
 from oracle.make_config_golden import REF, reference_functions  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
-SIZES = dict(T=11, G=37, Q=1)
+SIZES = dict(T=11, G=36, Q=1)
 
 
 class SmallDataModule:
