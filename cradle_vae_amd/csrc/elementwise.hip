@@ -34,12 +34,13 @@ struct NoisePlan {
 
 __global__ __launch_bounds__(256) void draw_noise_kernel(NoisePlan np, uint32_t plated_lo, uint32_t plated_hi,
                                                          uint32_t local_lo, uint32_t local_hi, uint32_t step_lo,
-                                                         uint32_t step_hi) {
-  const int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (ch >= np.chunk0[4]) return;
+                                                         uint32_t step_hi, int64_t ch_begin, int64_t ch_end, int which) {
+  const int64_t ch = ch_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ch >= ch_end) return;
   int k = 0;
 #pragma unroll
   for (int i = 1; i < 4; ++i) k += ch >= np.chunk0[i] ? 1 : 0;
+  if (!((which >> k) & 1)) return;
   const int64_t local = ch - np.chunk0[k];
   const Philox ph = k == 3 ? Philox{local_lo, local_hi} : Philox{plated_lo, plated_hi};
   const uint4 r = ph((uint32_t)local, (uint32_t)(local >> 32) | ((uint32_t)k << 28), step_lo, step_hi);
@@ -63,16 +64,24 @@ __global__ __launch_bounds__(256) void draw_noise_kernel(NoisePlan np, uint32_t 
   }
 }
 
+// which: bit k set = draw tensor k of {u_mask, eps_E, eps_qc_E, eps_z}.  A value depends on (seed, step, tensor,
+// position) only, so drawing the tensors in separate launches (on different streams) gives the same numbers.
 int draw_noise(float* u_mask, float* eps_E, float* eps_qc_E, float* eps_z, int64_t n_mask, int64_t n_qc, int64_t n_z,
-               uint64_t seed_plated, uint64_t seed_local, uint64_t step, hipStream_t stream) {
+               uint64_t seed_plated, uint64_t seed_local, uint64_t step, int which, hipStream_t stream) {
   NoisePlan np;
   np.dst[0] = u_mask; np.dst[1] = eps_E; np.dst[2] = eps_qc_E; np.dst[3] = eps_z;
   np.n[0] = n_mask; np.n[1] = n_mask; np.n[2] = n_qc; np.n[3] = n_z;
   np.chunk0[0] = 0;
   for (int k = 0; k < 4; ++k) np.chunk0[k + 1] = np.chunk0[k] + (np.n[k] + 3) / 4;
-  hipLaunchKernelGGL(draw_noise_kernel, dim3((unsigned)((np.chunk0[4] + 255) / 256)), dim3(256), 0, stream, np,
+  int first = 0, last = 3;
+  while (first < 4 && !((which >> first) & 1)) ++first;
+  while (last >= 0 && !((which >> last) & 1)) --last;
+  if (first > last) return CRADLE_OK;
+  const int64_t ch_begin = np.chunk0[first], ch_end = np.chunk0[last + 1];
+  if (ch_end == ch_begin) return CRADLE_OK;
+  hipLaunchKernelGGL(draw_noise_kernel, dim3((unsigned)((ch_end - ch_begin + 255) / 256)), dim3(256), 0, stream, np,
                      (uint32_t)seed_plated, (uint32_t)(seed_plated >> 32), (uint32_t)seed_local,
-                     (uint32_t)(seed_local >> 32), (uint32_t)step, (uint32_t)(step >> 32));
+                     (uint32_t)(seed_local >> 32), (uint32_t)step, (uint32_t)(step >> 32), ch_begin, ch_end, which);
   CRADLE_CHECK_LAUNCH("draw_noise_kernel");
   return CRADLE_OK;
 }
@@ -680,12 +689,16 @@ __global__ __launch_bounds__(256) void gaussE_bwd_kernel(const int* __restrict__
     }
     const int64_t i = row * L + l;
     const GaussVals g = gauss_vals(heads[row * 2 * L + l], heads[row * 2 * L + L + l]);
-    const float s = E[i], ep = eps[((int64_t)pp * T + t) * L + l];
+    // E and its scale are recomputed from the heads (same expressions as gaussE_fwd_kernel) when the caller
+    // passes none: the forward bookkeeping kernel then is a leaf that need not have run before this one
+    const float ep = eps[((int64_t)pp * T + t) * L + l];
+    const float s = E ? E[i] : gauss_draw(g, ep);
+    const float sdv = sd ? sd[i] : g.sd;
     const float pl = ploc[t * L + l], ps = pscale[t * L + l];
     const float ds = dme * mask[i] + coef * (-(s - pl) / (ps * ps));
     dmask[i] = dme * s;
     float dmean, dlv;
-    gauss_head_grads(g, ds, ep, coef / sd[i], dmean, dlv);
+    gauss_head_grads(g, ds, ep, coef / sdv, dmean, dlv);
     dheads[row * 2 * L + l] = dmean;
     dheads[row * 2 * L + L + l] = dlv;
   }
@@ -1008,11 +1021,13 @@ __global__ __launch_bounds__(256) void enc_combine_bwd_vq_kernel(const float* __
   }
 }
 
+// which: 1 = the (doffW, dxW) kernel on `stream`, 2 = the dvq kernel on `vq_stream`, 3 = both
 int enc_combine_bwd(const float* dpre, const float* qc, float* doffW, float* dxW, float* dvq, int P, int N, int Q, int H,
-                    hipStream_t stream, hipStream_t vq_stream) {
-  hipLaunchKernelGGL(enc_combine_bwd_kernel, dim3(N), dim3(128), 0, stream, dpre, doffW, dxW, P, N, H);
-  hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3((H + 15) / 16, 2 * P * Q), dim3(256), 0, vq_stream, dpre, qc, dvq,
-                     P, N, Q, H);
+                    hipStream_t stream, hipStream_t vq_stream, int which) {
+  if (which & 1) hipLaunchKernelGGL(enc_combine_bwd_kernel, dim3(N), dim3(128), 0, stream, dpre, doffW, dxW, P, N, H);
+  if (which & 2)
+    hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3((H + 15) / 16, 2 * P * Q), dim3(256), 0, vq_stream, dpre, qc, dvq,
+                       P, N, Q, H);
   CRADLE_CHECK_LAUNCH("enc_combine_bwd");
   return CRADLE_OK;
 }

@@ -119,24 +119,91 @@ struct TileLoader {
   }
 };
 
-// The fused epilogue of one output element (shared by the GEMM kernel and the split-K reducer).
-__device__ __forceinline__ void epilogue(const GemmParams& p, int row, int col, float v) {
-  if (col == p.N) {  // virtual ones column -> bias gradient
-    p.extra_col[row] = v + (p.beta != 0.f ? p.beta * p.extra_col[row] : 0.f);
-    return;
+// The fused epilogue of NE output elements of one thread (shared by the GEMM kernel and the split-K reducer).
+// Every feature is handled for all NE elements at once -- its NE loads are issued back to back and waited
+// for once -- instead of element by element: with the features behind run-time branches, the element-wise
+// form serialises up to 3 dependent global-load latencies per element, 16 elements per lane, which was
+// most of the fixed cost of the small products.  Loads of elements outside the matrix go to a clamped
+// (valid) address; only the stores are guarded.  Per element the arithmetic is, in this order:
+//   v + bias[col] + (rowscale ? rowscale * rowbias : rowbias) -> LeakyReLU -> (act_out) -> + res -> + beta*C
+template <int NE>
+__device__ __forceinline__ void epilogue_batch(const GemmParams& p, const int (&row_in)[NE], const int (&col_in)[NE],
+                                               const bool (&ok)[NE], float (&v)[NE]) {
+  int row[NE], col[NE];
+  bool ones[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    ones[e] = col_in[e] == p.N;  // virtual ones column -> bias gradient
+    row[e] = ok[e] ? row_in[e] : 0;
+    col[e] = ok[e] && !ones[e] ? col_in[e] : 0;
   }
-  if (p.bias) v += p.bias[col];
+  if (p.extra_col) {
+    float old[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) old[e] = (p.beta != 0.f && ones[e]) ? p.extra_col[row[e]] : 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+      if (ok[e] && ones[e]) p.extra_col[row[e]] = v[e] + (p.beta != 0.f ? p.beta * old[e] : 0.f);
+  }
+  if (p.bias) {
+    float b[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) b[e] = p.bias[col[e]];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] += b[e];
+  }
   if (p.rowbias) {
-    const int rb_row = p.rb_mode == 1 ? row / p.rb_n : row % p.rb_n;
-    const float rb = p.rowbias[(int64_t)rb_row * p.ld_rb + col];
-    v += p.rowscale ? p.rowscale[row % p.rs_n] * rb : rb;
+    float rb[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int rb_row = p.rb_mode == 1 ? row[e] / p.rb_n : row[e] % p.rb_n;
+      rb[e] = p.rowbias[(int64_t)rb_row * p.ld_rb + col[e]];
+    }
+    if (p.rowscale) {
+      float rs[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) rs[e] = p.rowscale[row[e] % p.rs_n];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) v[e] += rs[e] * rb[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) v[e] += rb[e];
+    }
   }
-  if (p.act) v = v > 0.f ? v : kLeakySlope * v;
-  if (p.act_out) p.act_out[(int64_t)row * p.ld_act + col] = v;
-  if (p.res) v += p.res[(int64_t)row * p.ld_res + col];
-  if (p.beta != 0.f) v += p.beta * p.C[(int64_t)row * p.ldc + col];
-  p.C[(int64_t)row * p.ldc + col] = v;
-  if (p.C2) p.C2[(int64_t)row * p.ldc2 + col] = v * (p.dact_src[(int64_t)row * p.ld_ds + col] > 0.f ? 1.f : kLeakySlope);
+  if (p.act) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] = v[e] > 0.f ? v[e] : kLeakySlope * v[e];
+  }
+  if (p.act_out) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+      if (ok[e] && !ones[e]) p.act_out[(int64_t)row[e] * p.ld_act + col[e]] = v[e];
+  }
+  if (p.res) {
+    float r[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) r[e] = p.res[(int64_t)row[e] * p.ld_res + col[e]];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] += r[e];
+  }
+  if (p.beta != 0.f) {
+    float c[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) c[e] = p.C[(int64_t)row[e] * p.ldc + col[e]];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] += p.beta * c[e];
+  }
+#pragma unroll
+  for (int e = 0; e < NE; ++e)
+    if (ok[e] && !ones[e]) p.C[(int64_t)row[e] * p.ldc + col[e]] = v[e];
+  if (p.C2) {
+    float d[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) d[e] = p.dact_src[(int64_t)row[e] * p.ld_ds + col[e]];
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+      if (ok[e] && !ones[e]) p.C2[(int64_t)row[e] * p.ldc2 + col[e]] = v[e] * (d[e] > 0.f ? 1.f : kLeakySlope);
+  }
 }
 
 // WK = 2: eight waves per workgroup; waves 4-7 take the second half of every K step of the same
@@ -193,17 +260,23 @@ __global__ __launch_bounds__(64 * WS * WS * WK) void gemm_f32_kernel(const GemmP
   // Register prefetch ring of D K-steps: the global loads of step kt+D are issued as soon as
   // the registers of step kt have been written to LDS, so D-1 steps of MFMA work cover the
   // L2/HBM latency even with a single wave per SIMD.  The step count is rounded up to a
-  // multiple of D; steps past the end load zeros (select, no branch), which the MFMAs absorb.
+  // multiple of D; steps past the end load zeros (range check, no branch), which the MFMAs absorb
+  // (leaving the last ring turn early instead costs the 64x64 kernels 24 VGPRs: occupancy 8 -> 6).
   LA la[D];
   LB lb[D];
   const int ones_row = p.extra_col ? p.N : -1;
   const int k_limit = min(p.K, kt_end * BK);  // this split's K range ends here
   const int n_steps = (kt_end - kt_begin + D - 1) / D * D;
   const int ones_b = B_KMAJOR ? -1 : ones_row;
+  // The ring's loads must be ISSUED in ring order, here as in the loop: the wait before the LDS store of
+  // step st is then "all but the (D-1) younger steps' loads" (s_waitcnt vmcnt(2(D-1)NV)).  Left alone, the
+  // scheduler interleaves the prologue's loads by address computation, and the wait at the loop head --
+  // which has to hold for the prologue's order as well -- becomes vmcnt(0): no prefetch distance at all.
 #pragma unroll
   for (int st = 0; st < D; ++st) {
     la[st].template load<VEC>(p.A, p.lda, p.a_bytes, row0, (kt_begin + st) * BK, p.M, k_limit);
     lb[st].template load<VEC>(p.B, p.ldb, p.b_bytes, col0, (kt_begin + st) * BK, p.N, k_limit);
+    __builtin_amdgcn_sched_barrier(0);
   }
   for (int kt = kt_begin; kt < kt_begin + n_steps; kt += D) {
 #pragma unroll
@@ -268,12 +341,29 @@ __global__ __launch_bounds__(64 * WS * WS * WK) void gemm_f32_kernel(const GemmP
     for (int j = 0; j < TN; ++j) {
       const int col = col0 + (wn * TN + j) * 32 + li;
       if (col >= Np) continue;
+      if (p.splitk > 1) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = row0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (row >= p.M) continue;
-        if (p.splitk > 1) p.partial[(int64_t)blockIdx.z * p.slab + (int64_t)row * Np + col] = acc[i][j][e];
-        else epilogue(p, row, col, acc[i][j][e]);
+        for (int e = 0; e < 16; ++e) {
+          const int row = row0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (row < p.M) p.partial[(int64_t)blockIdx.z * p.slab + (int64_t)row * Np + col] = acc[i][j][e];
+        }
+        continue;
+      }
+      // CH elements per batch: all 16 at once costs ~80 more VGPRs (a wave of occupancy on the large kernels)
+      constexpr int CH = WS == 2 ? 1 : 8;
+#pragma unroll
+      for (int e0 = 0; e0 < 16; e0 += CH) {
+        int rows[CH], cols[CH];
+        bool ok[CH];
+        float v[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          rows[e] = row0 + (wm * TM + i) * 32 + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2) + 4 * lh;
+          cols[e] = col;
+          ok[e] = rows[e] < p.M;
+          v[e] = acc[i][j][e0 + e];
+        }
+        epilogue_batch<CH>(p, rows, cols, ok, v);
       }
     }
 }
@@ -292,12 +382,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
   }
   int row = (int)(idx / Np), col = (int)(idx % Np);
-  const float vals[4] = {v.x, v.y, v.z, v.w};
+  int rows[4], cols[4];
+  bool ok[4];
+  float vals[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    if (idx + e < total) epilogue(p, row, col, vals[e]);
+    rows[e] = row; cols[e] = col; ok[e] = idx + e < total;
     if (++col == Np) { col = 0; ++row; }
   }
+  epilogue_batch<4>(p, rows, cols, ok, vals);
 }
 
 // ws = 2: 2x2 waves per K group (tile 64*tm x 64*tn); ws = 1: one wave per K group (tile 32*tm x 32*tn)
@@ -324,6 +417,9 @@ static bool launch_cfg(const GemmParams& p, int ws, int tm, int tn, int bk, int 
   CRADLE_GEMM_CASE(1, 1, 1, 32, 2, 4)
   CRADLE_GEMM_CASE(1, 1, 1, 32, 4, 4)
   CRADLE_GEMM_CASE(1, 1, 1, 64, 2, 4)
+  CRADLE_GEMM_CASE(1, 1, 1, 64, 4, 4)
+  CRADLE_GEMM_CASE(1, 1, 1, 32, 8, 4)
+  CRADLE_GEMM_CASE(2, 1, 1, 32, 4, 1)
   CRADLE_GEMM_CASE(1, 1, 2, 32, 2, 4)
   CRADLE_GEMM_CASE(1, 2, 2, 32, 2, 4)
 #undef CRADLE_GEMM_CASE

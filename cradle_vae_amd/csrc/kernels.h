@@ -97,7 +97,7 @@ int cell_prep(const float* qc, const float* D_obs, const float* qc_obs, const in
 
 // u_mask, eps_E (n_mask each), eps_qc_E (n_qc), eps_z (n_z): Philox draws keyed by (seed, step)
 int draw_noise(float* u_mask, float* eps_E, float* eps_qc_E, float* eps_z, int64_t n_mask, int64_t n_qc, int64_t n_z,
-               uint64_t seed_plated, uint64_t seed_local, uint64_t step, hipStream_t stream);
+               uint64_t seed_plated, uint64_t seed_local, uint64_t step, int which, hipStream_t stream);
 
 int log_standardize(const float* X, const float* cfX, const float* log_mean, const float* log_scale, float* xn,
                     float* hascf, int N, int G, hipStream_t stream);
@@ -135,7 +135,7 @@ int enc_combine_fwd(const float* xW, const float* offW, const float* vq, const f
                     int P, int N, int Q, int H, hipStream_t stream);
 // dvq (the qc-embedding part) is produced on `vq_stream`: its consumers are off the critical path
 int enc_combine_bwd(const float* dpre, const float* qc, float* doffW, float* dxW, float* dvq, int P, int N, int Q, int H,
-                    hipStream_t stream, hipStream_t vq_stream);
+                    hipStream_t stream, hipStream_t vq_stream, int which = 3);
 
 // ---- elementwise.hip : small helpers
 int transpose_cols(const float* W, int64_t ldw, int rows, int col0, int cols, float* out, hipStream_t stream);

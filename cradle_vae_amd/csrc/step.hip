@@ -28,8 +28,6 @@ using namespace cradle;
 namespace {
 
 // Schedule experiments (tools only): CRADLE_SCHED is a bit mask read once.
-//   1: the decoder output layer's weight gradient is forked only after its data gradient (and that one's
-//      split-K reduction) has finished, so that the critical chain has the chip to itself for its largest kernel
 //   2: no side streams at all (everything on the caller's stream)
 // cradle_step_debug_stop_after(k): the step returns (all streams joined) right after its k-th checkpoint;
 // timing the truncated step in a steady-state loop gives the cumulative cost of its phases, boundaries and
@@ -220,8 +218,9 @@ int get_streams(StreamSet** out) {
       cradle_set_error("elbo_step: marker stream creation failed");
       return CRADLE_ERR_HIP;
     }
-    unsigned evflags = hipEventDisableTiming;
-    if (getenv("CRADLE_EVFLAGS")) evflags |= (unsigned)strtoul(getenv("CRADLE_EVFLAGS"), nullptr, 0);
+    // fork/join events order kernels of one device: no system-scope release (a record costs the stream it is
+    // made on 3.4 us instead of 4.8 us between two dependent kernels, tools/micro/event_cost.hip)
+    const unsigned evflags = hipEventDisableTiming | hipEventDisableSystemFence;
     for (int i = 0; i < kMaxEvents; ++i)
       if (hipEventCreateWithFlags(&ss.ev[i], evflags) != hipSuccess) {
         cradle_set_error("elbo_step: event creation failed");
@@ -331,38 +330,60 @@ void head_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, int Nout, const fl
 // Backward through the output layer and trunk layers n-1..1 on stream `q`.  dout: (M, Nout)
 // gradient of the output layer's result.  Writes dW_head, db_head, dW[k], db[k] (k >= 1) and
 // returns da_0 = dL/d(pre-activation of layer 0) in (M, H).  The data-gradient chain stays on
-// `q`; each weight-gradient GEMM is forked to side stream `wq` (alternating `wq`/`wq2`) as soon
-// as its da_k exists.  Pass wq == q to keep everything on one stream.
+// `q`; the weight-gradient GEMMs run on the side streams `wq` / `wq2` (pass wq == q to keep everything on
+// one stream).  An event record between two dependent kernels costs the recording stream 3-5 us, so the
+// chain is not interrupted once per layer: the output layer's weight gradient forks at `ev_dout` (a point on
+// `q` where dout exists; null: recorded here); the trunk layers' fork in groups of `layers_per_fork` (0: all
+// at one event after the last data gradient).  The event recorded after the last data gradient, if any, is
+// handed back in *ev_done (else null) for the caller's own forks.
 const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, int M, int H, int Nout,
                             const float* dout, float* const* y, float* const* r, float* const* Gb, float* const* da,
-                            int q, int wq, int wq2, void* ev_head_done = nullptr, bool delay_head_wgrad = false) {
+                            int q, int wq, int wq2, hipEvent_t ev_dout = nullptr, hipEvent_t* ev_done = nullptr,
+                            void* ev_head_done = nullptr, int layers_per_fork = 0) {
   const int n = m.n_layers;
-  int side = wq;
-  auto wgrad = [&](GemmParams p) {
-    if (side != q) c.after(side, q);
-    c.gemm(GEMM_TN, p, side);
-    side = side == wq ? wq2 : wq;
-  };
-  const bool head_wgrad_last = delay_head_wgrad;
-  auto head_wgrad = [&]() {  // dW_head = dout^T y_last, db_head = colsum(dout)
+  const bool forked = wq != q;
+  if (ev_done) *ev_done = nullptr;
+  {  // dW_head = dout^T y_last, db_head = colsum(dout)
     GemmParams p = gp(dout, Nout, y[n - 1], H, g.W_head, H, Nout, H, M);
     p.extra_col = g.b_head;
-    wgrad(p);
+    if (forked) {
+      if (!ev_dout) ev_dout = c.record(q);
+      c.wait(wq, ev_dout);
+    }
+    c.gemm(GEMM_TN, p, wq);
     mark_all(c, ev_head_done);  // the output layer's gradients have been enqueued
+  }
+  int side = wq2;  // the output layer's product went to wq
+  auto wgrad = [&](int k, int stream) {  // dW_k = da_k^T y_{k-1}
+    GemmParams p = gp(da[k], H, y[k - 1], H, g.W[k], H, H, H, M);
+    p.extra_col = g.b[k];
+    c.gemm(GEMM_TN, p, stream);
   };
-  if (!head_wgrad_last) head_wgrad();
+  int pending[CRADLE_MAX_LAYERS], n_pending = 0;
+  auto flush = [&]() {  // one event for every weight gradient whose da exists by now
+    if (!n_pending) return;
+    hipEvent_t e = c.record(q);
+    c.wait(wq, e);
+    if (wq2 != wq) c.wait(wq2, e);
+    for (int i = 0; i < n_pending; ++i) {
+      wgrad(pending[i], side);
+      side = side == wq ? wq2 : wq;
+    }
+    n_pending = 0;
+    if (ev_done) *ev_done = e;
+  };
   int cur = 0;
   {  // G_{n-1} = dout W_head ; da_{n-1} = G_{n-1} * slope(r_{n-1})
     GemmParams p = gp(dout, Nout, m.W_head, H, Gb[cur], H, M, H, Nout);
     p.dact_src = n > 1 ? r[n - 1] : y[0]; p.ld_ds = H; p.C2 = da[n - 1]; p.ldc2 = H;
     c.gemm(GEMM_NN, p, q);
   }
-  if (head_wgrad_last) head_wgrad();
   for (int k = n - 1; k >= 1; --k) {
-    {  // dW_k = da_k^T y_{k-1}
-      GemmParams p = gp(da[k], H, y[k - 1], H, g.W[k], H, H, H, M);
-      p.extra_col = g.b[k];
-      wgrad(p);
+    if (!forked) wgrad(k, q);
+    else {
+      if (ev_done) *ev_done = nullptr;  // a data gradient follows: an earlier event no longer is "the end"
+      if (layers_per_fork > 0 && n_pending == layers_per_fork) flush();
+      pending[n_pending++] = k;
     }
     {  // G_{k-1} = da_k W_k + G_k ; da_{k-1} = G_{k-1} * slope(r_{k-1})   (r_0 = y_0)
       GemmParams p = gp(da[k], H, m.W[k], H, Gb[cur ^ 1], H, M, H, H);
@@ -372,6 +393,7 @@ const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_p
     }
     cur ^= 1;
   }
+  flush();
   return da[0];
 }
 
@@ -475,33 +497,38 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
 
   {
   // ================================================================== forward
-  // stream 1: log-standardise X and cfX, x Wx^T (the longest side chain: it starts at once), then what only
-  //           the loss weights and the backward scatter need (CSC columns, per-cell weights).
-  // stream 2: dosage plan, per-gene constants, q(qc_E).
+  // stream 1: dosage plan (three short launches; stream 0 needs it at the gather, or -- compact axis -- at once),
+  //           log-standardise X and cfX, x Wx^T, then what only the loss weights and the backward scatter need
+  //           (CSC columns, per-cell weights).
+  // stream 2: q(qc_E) -- a chain of ten launches on a handful of rows, the longest path to the join when anything
+  //           else shares its stream -- and, last, the per-gene constants K1 reads.
   // stream 0 (caller's): the step's noise, q(M), q(E|M), gathers -- then joins both.
-  c.after(1, 0);
-  c.after(2, 0);
+  {
+    hipEvent_t e = c.record(0);  // one record on the caller's stream for both forks
+    c.wait(1, e);
+    c.wait(2, e);
+  }
+  STEP(build_dosage_plan(d.D, N, T, w.plan, s1));
+  hipEvent_t ev_plan = c.record(1);
   STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s1));
   c.gemm(GEMM_NT, gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G), 1);  // x Wx^T, X and cfX
-  // Full treatment axis: stream 0 starts with q(M) / q(E|M) straight away and meets the plan at
-  // the gather.  Compact axis: q(M) needs the slot map, so stream 0 waits for the plan's first part.
-  STEP(build_dosage_plan(d.D, N, T, w.plan, s2));
-  hipEvent_t ev_plan = c.record(2);
-  c.wait(1, ev_plan);
+  hipEvent_t ev_xw = c.record(1);
   STEP(build_dosage_plan_csc(N, T, w.plan, s1));
   STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, Tc, w.plan.tmap,
                  s1));
-  if (own_noise)
+  // the step's own noise: q(qc_E)'s on the stream that reads it, the rest on the caller's -- no event between them
+  if (own_noise) {
     STEP(draw_noise(w.u_mask, w.eps_E, w.eps_qc_E, w.eps_z, (int64_t)PP * T * L, (int64_t)PP * Q * L, (int64_t)PN * L,
-                    d.rng_seed_plated, d.rng_seed_local, d.rng_step, s));
-  hipEvent_t ev_noise = own_noise ? c.record(0) : nullptr;  // stream 2's q(qc_E) draw reads eps_qc_E
+                    d.rng_seed_plated, d.rng_seed_local, d.rng_step, 1 | 2 | 8, s));
+    STEP(draw_noise(w.u_mask, w.eps_E, w.eps_qc_E, w.eps_z, (int64_t)PP * T * L, (int64_t)PP * Q * L, (int64_t)PN * L,
+                    d.rng_seed_plated, d.rng_seed_local, d.rng_step, 4, s2));
+  }
 
   hipEvent_t ev_w0t = nullptr;
   if (!w.plan.tmap) {  // one-hot block of the embedding encoder's first layer as a (T, Hm) table: weights only
     STEP(transpose_cols(d.emb.W[0], L + T, Hm, L, T, w.W0tT, s2));
     ev_w0t = c.record(2);
   }
-  STEP(cradle_nb_gene_consts(d.log_concentration, w.gene_consts, G, s2));
   hipLaunchKernelGGL(fill_kernel, dim3((Q * L + 255) / 256), dim3(256), 0, s2, w.ones_q, (int64_t)Q * L, 1.0f);
   {  // q(qc_E): constant input ones(Q, L)
     GemmParams p = gp(w.ones_q, L, d.qce.W[0], L, w.yq[0], Hm, Q, Hm, L);
@@ -511,10 +538,12 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   trunk_fwd(c, d.qce, Q, Hm, w.yq, w.rq, 2);
   head_fwd(c, d.qce, Q, Hm, 2 * L, w.yq[d.qce.n_layers - 1], w.headsq, 2);
   if (c.rc) return c.rc;
-  c.wait(2, ev_noise);
   STEP(qce_fwd(w.headsq, nz_q, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.Sq, w.qsum, PP, P, Q, L, s2));
   c.gemm(GEMM_NT, gp(w.qcE, L, Wenc0 + G + L, ldenc, w.vq, He, PP * Q, He, L), 2);  // qc_E Wqc^T
+  hipEvent_t ev_vq = c.record(2);
   c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L), 2);        // bad-variant shift per particle
+  STEP(cradle_nb_gene_consts(d.log_concentration, w.gene_consts, G, s2));
+  hipEvent_t ev_s2 = c.record(2);
 
   if (w.plan.tmap) c.wait(0, ev_plan);
   STEP(mask_fwd(d.q_mask_logits, nz_u, d.p_mask_probs, d.temperature, w.mask, w.soft, w.Smask, PP, T, Tc, w.plan.tmap,
@@ -533,27 +562,27 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   head_fwd(c, d.emb, PT, Hm, 2 * L, w.yE[d.emb.n_layers - 1], w.headsE);
   if (c.rc) return c.rc;
   if (g_stop_after == 2) { c.after(0, 1); c.after(0, 2); return c.rc; }
-  // E, its scale and the log-ratio sums are needed by the loss and the backward pass only: stream 2 (idle by
-  // now); the gather below draws the E it needs from the heads itself
-  c.after(2, 0);
-  STEP(gaussE_fwd(w.headsE, nz_E, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.SE, PP, T, Tc, w.plan.tmap, L, s2));
+  // (E, its scale and the log-ratio sums are needed by the loss only -- the gather below and the backward pass
+  // draw the E they need from the heads themselves -- and are made on stream 2 after K1, at a fork that exists anyway)
   if (!w.plan.tmap) c.wait(0, ev_plan);
   STEP(gather_offsets(w.headsE, nz_E, w.mask, w.plan, w.zoff + L, 2 * L, w.offB, L, PP, P, N, T, L, s));  // D @ (mask*E)
   c.gemm(GEMM_NT, gp(w.offB, L, Wenc0 + G, ldenc, w.offW, He, 2 * PN, He, L));  // offsets . Woff^T, both passes
-  c.after(0, 1);
-  c.after(0, 2);
+  c.wait(0, ev_xw);  // the encoders need x Wx^T and qc_E Wqc^T; the rest of both side streams is met at the decoder
+  c.wait(0, ev_vq);
   if (c.rc) return c.rc;
-  if (g_stop_after == 3) return c.rc;
+  if (g_stop_after == 3) { c.after(0, 1); c.after(0, 2); return c.rc; }
 
   // basal encoder (three variants), z_basal, counterfactual KL
   STEP(enc_combine_fwd(w.xW, w.offW, w.vq, d.enc.b[0], d.qc, w.yz[0], P, N, Q, He, s));
   trunk_fwd(c, d.enc, 3 * PN, He, w.yz, w.rz);
   head_fwd(c, d.enc, 3 * PN, He, 2 * L, w.yz[d.enc.n_layers - 1], w.headsz);
   if (c.rc) return c.rc;
-  if (g_stop_after == 4) return c.rc;
+  if (g_stop_after == 4) { c.after(0, 1); c.after(0, 2); return c.rc; }
   STEP(zhead_fwd(w.headsz, nz_z, w.hascf, d.beta, w.zoff, 2 * L, w.sdz, w.ltz, w.klrow, w.dheadsz, P, N, L, s));
 
-  // decoder, live variant per cell
+  // decoder, live variant per cell (per-cell weights: stream 1; bad-variant shift, gene constants: stream 2)
+  c.after(0, 1);
+  c.wait(0, ev_s2);
   {
     GemmParams p = gp(w.zoff, 2 * L, Wd0, 3 * L, w.yd[0], Hd, PN, Hd, 2 * L);
     p.bias = d.dec.b[0]; p.act = 1; p.rowbias = w.wq; p.ld_rb = Hd; p.rb_mode = 1; p.rb_n = N;
@@ -579,8 +608,11 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
                                          d.ev_k1_end, s));
   }
   }
-  // the loss scalars and d log_c are leaves of the graph: stream 2, beside the backward pass
-  c.after(2, 0);
+  // the loss scalars, d log_c and the q(E|M) bookkeeping are leaves of the graph: stream 2, beside the backward
+  // pass; the same event forks the output layer's weight gradient to stream 1
+  hipEvent_t ev_k1 = c.record(0);
+  c.wait(2, ev_k1);
+  STEP(gaussE_fwd(w.headsE, nz_E, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.SE, PP, T, Tc, w.plan.tmap, L, s2));
   if (d.compute_grads) STEP(nb_dlogc_reduce(w.nbws, N * cradle_nb_particle_split(P, N), G, d.d_log_concentration, 0, s2));
   STEP(finalize_loss(w.recon, w.cp.wrec, w.ltz, w.klrow, w.Smask, w.SE, w.Sq, w.cp.cwc, w.cp.cwq, d.beta, P, N, Tc, Q,
                      d.flags, d.out, s2));
@@ -590,13 +622,15 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   }
 
   // ================================================================== backward
-  // The data-gradient chain runs on stream 0; every weight-gradient GEMM is forked to a side
-  // stream as soon as its inputs exist.  All streams are joined before returning.
+  // The data-gradient chain runs on stream 0; the weight-gradient GEMMs are forked to the side streams at as few
+  // events as possible (see head_trunk_bwd).  All streams are joined before returning.
   // decoder: logits now hold d loss / d logits
-  const float* da0d = head_trunk_bwd(c, d.dec, d.d_dec, PN, Hd, G, w.logits, w.yd, w.rd, w.Gd, w.dad, 0, 1, 2,
-                                     d.ev_bucket[0], (sched_flags() & 1) != 0);  // (d log_c was enqueued on stream 2 above)
+  hipEvent_t ev_dec = nullptr;
+  const float* da0d = head_trunk_bwd(c, d.dec, d.d_dec, PN, Hd, G, w.logits, w.yd, w.rd, w.Gd, w.dad, 0, 1, 2, ev_k1,
+                                     &ev_dec, d.ev_bucket[0]);
   if (c.rc) return c.rc;
-  c.after(2, 0);
+  if (!ev_dec) ev_dec = c.record(0);
+  c.wait(2, ev_dec);
   {  // dW0[:, :2L] = da0^T [z | off], db0
     GemmParams p = gp(da0d, Hd, w.zoff, 2 * L, d.d_dec.W[0], 3 * L, Hd, 2 * L, PN);
     p.extra_col = d.d_dec.b[0];
@@ -614,17 +648,20 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   STEP(zhead_bwd(w.headsz, nz_z, w.zoff, 2 * L, w.sdz, w.dzoff, 2 * L, w.dheadsz, P, N, L, s));
   const float* dpre = head_trunk_bwd(c, d.enc, d.d_enc, 3 * PN, He, 2 * L, w.dheadsz, w.yz, w.rz, w.Gz, w.daz, 0, 1, 2);
   if (c.rc) return c.rc;
-  c.after(2, 0);  // dvq on stream 2: it feeds dWqc and q(qc_E) only
-  STEP(enc_combine_bwd(dpre, d.qc, w.doffW, w.dxW, w.dvq, P, N, Q, He, s, s2));
+  STEP(enc_combine_bwd(dpre, d.qc, w.doffW, w.dxW, w.dvq, P, N, Q, He, s, s2, 1));
   float* dWenc0 = d.d_enc.W[0];
-  c.after(1, 0);
-  c.after(2, 0);
+  {
+    hipEvent_t e = c.record(0);  // dpre, doffW, dxW exist
+    c.wait(1, e);
+    c.wait(2, e);
+  }
+  STEP(enc_combine_bwd(dpre, d.qc, w.doffW, w.dxW, w.dvq, P, N, Q, He, s, s2, 2));  // dvq: feeds dWqc and q(qc_E) only
   {  // dWx = dxW^T logstd([X; cfX]); db0 = colsum(dxW)
     GemmParams p = gp(w.dxW, He, w.xn, G, dWenc0, ldenc, He, G, 2 * N);
     p.extra_col = d.d_enc.b[0];
     c.gemm(GEMM_TN, p, 1);
   }
-  c.gemm(GEMM_TN, gp(w.doffW, He, w.offB, L, dWenc0 + G, ldenc, He, L, 2 * PN), 2);  // dWoff = doffW^T [offA; offB]
+  c.gemm(GEMM_TN, gp(w.doffW, He, w.offB, L, dWenc0 + G, ldenc, He, L, 2 * PN), 1);  // dWoff = doffW^T [offA; offB]
   c.gemm(GEMM_TN, gp(w.dvq, He, w.qcE, L, dWenc0 + G + L, ldenc, He, L, PP * Q), 2);      // dWqc
   mark_all(c, d.ev_bucket[2]);  // every basal-encoder gradient has been enqueued
   c.gemm(GEMM_NN, gp(w.doffW, He, Wenc0 + G, ldenc, w.doffenc, L, 2 * PN, L, He));        // d offsets via encoder
@@ -642,12 +679,16 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   }
   if (c.rc) return c.rc;
 
-  // q(E|M), q(M)
+  // q(E|M), q(M)  (E and its scale are recomputed from the heads: stream 2's bookkeeping kernel is not waited for)
   STEP(gaussE_bwd(w.plan, w.dzoff + L, 2 * L, w.doffenc, L, w.doffenc + (int64_t)PN * L, L, w.headsE, nz_E, w.mask,
-                  d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.cp.coefTc, w.dheadsE, w.dmaskME, PP, P, N, T, L, s));
-  const float* da0E = head_trunk_bwd(c, d.emb, d.d_emb, PT, Hm, 2 * L, w.dheadsE, w.yE, w.rE, w.GE, w.daE, 0, 1, 1);
+                  d.p_E_loc, d.p_E_scale, nullptr, nullptr, w.cp.coefTc, w.dheadsE, w.dmaskME, PP, P, N, T, L, s));
+  hipEvent_t ev_emb = nullptr;
+  // (the step's tail: nothing else is left to hide a late weight gradient behind, so these fork in twos)
+  const float* da0E = head_trunk_bwd(c, d.emb, d.d_emb, PT, Hm, 2 * L, w.dheadsE, w.yE, w.rE, w.GE, w.daE, 0, 1, 2, nullptr,
+                                     &ev_emb, nullptr, 2);
   if (c.rc) return c.rc;
-  c.after(1, 0);
+  if (!ev_emb) ev_emb = c.record(0);
+  c.wait(1, ev_emb);
   {  // dW0[:, :L] = da0^T mask, db0
     GemmParams p = gp(da0E, Hm, w.mask, L, d.d_emb.W[0], L + T, Hm, L, PT);
     p.extra_col = d.d_emb.b[0];

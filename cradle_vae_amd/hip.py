@@ -11,7 +11,9 @@ from typing import Optional
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libcradle_hip.so")
+# CRADLE_HIP_LIB: another build of the same library (A/B timing runs of two builds on one GPU box, tools/ only)
+_LIB_PATH = os.environ.get("CRADLE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                                                             "libcradle_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
 c_float_p = ctypes.c_void_p

@@ -57,7 +57,7 @@ if args and args[0] == "--replogle":
 if args:
     shapes = [s for s in shapes if any(a in s[4] for a in args)]
 cfgs = [(2, 2, 16, 2, 1), (1, 1, 16, 2, 1), (1, 1, 16, 4, 1), (1, 1, 32, 2, 1), (1, 1, 32, 2, 2), (1, 1, 32, 4, 2), (1, 2, 32, 2, 2), (2, 2, 32, 2, 2),
-        (1, 1, 32, 2, 4), (1, 1, 32, 4, 4), (1, 1, 64, 2, 4), (1, 2, 32, 2, 4), (2, 2, 32, 2, 4)]
+        (1, 1, 32, 2, 4), (1, 1, 32, 4, 4), (1, 1, 32, 8, 4), (1, 1, 64, 2, 4), (1, 1, 64, 4, 4), (1, 1, 32, 4, 1), (1, 2, 32, 2, 4), (2, 2, 32, 2, 4)]
 splits = [1, 2, 4, 8, 16]
 for layout, M, N, K, what in shapes:
     if layout == ops.NT:
