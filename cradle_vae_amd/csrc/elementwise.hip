@@ -446,6 +446,8 @@ int cell_prep(const float* qc, const float* D_obs, const float* qc_obs, const in
 // K8 LogStandardizationModule.forward (normalization.py:41-45) for X and cfX in one launch,
 // plus the "has a counterfactual" flag of loss_modules.py:145 (cfX.sum(1) != 0).
 // =====================================================================================
+// One workgroup per row; VEC: 16-byte accesses, two per thread in flight (G % 4 == 0 and aligned pointers).
+template <bool VEC>
 __global__ __launch_bounds__(256) void log_standardize_kernel(const float* __restrict__ X, const float* __restrict__ cfX,
                                                               const float* __restrict__ mean, const float* __restrict__ scale,
                                                               float* __restrict__ xn, float* __restrict__ hascf, int N, int G) {
@@ -454,12 +456,33 @@ __global__ __launch_bounds__(256) void log_standardize_kernel(const float* __res
   const float* src = r < N ? X + (int64_t)r * G : cfX + (int64_t)(r - N) * G;
   float* dst = xn + (int64_t)r * G;
   float s = 0.f;
-  for (int g = threadIdx.x; g < G; g += 256) {
-    const float x = src[g];
-    s += x;
-    dst[g] = nan_to_num_ref((logf(x + 1.0f) - mean[g]) / scale[g]);
+  if (VEC) {
+    const int G4 = G / 4;
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    const float4* m4 = reinterpret_cast<const float4*>(mean);
+    const float4* s4 = reinterpret_cast<const float4*>(scale);
+    float4* dst4 = reinterpret_cast<float4*>(dst);
+    for (int g0 = threadIdx.x; g0 < G4; g0 += 512) {
+      const int g1 = g0 + 256;
+      const bool two = g1 < G4;
+      const float4 x0 = src4[g0], mu0 = m4[g0], sc0 = s4[g0];
+      const float4 x1 = two ? src4[g1] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 mu1 = two ? m4[g1] : x1, sc1 = two ? s4[g1] : make_float4(1.f, 1.f, 1.f, 1.f);
+      s += (x0.x + x0.y) + (x0.z + x0.w) + (x1.x + x1.y) + (x1.z + x1.w);
+      dst4[g0] = make_float4(nan_to_num_ref((logf(x0.x + 1.0f) - mu0.x) / sc0.x), nan_to_num_ref((logf(x0.y + 1.0f) - mu0.y) / sc0.y),
+                             nan_to_num_ref((logf(x0.z + 1.0f) - mu0.z) / sc0.z), nan_to_num_ref((logf(x0.w + 1.0f) - mu0.w) / sc0.w));
+      if (two)
+        dst4[g1] = make_float4(nan_to_num_ref((logf(x1.x + 1.0f) - mu1.x) / sc1.x), nan_to_num_ref((logf(x1.y + 1.0f) - mu1.y) / sc1.y),
+                               nan_to_num_ref((logf(x1.z + 1.0f) - mu1.z) / sc1.z), nan_to_num_ref((logf(x1.w + 1.0f) - mu1.w) / sc1.w));
+    }
+  } else {
+    for (int g = threadIdx.x; g < G; g += 256) {
+      const float x = src[g];
+      s += x;
+      dst[g] = nan_to_num_ref((logf(x + 1.0f) - mean[g]) / scale[g]);
+    }
   }
-  if (r >= N) {
+  if (r >= N) {  // counts are non-negative: the row sum is zero iff every entry is, whatever the order of the sum
     s = block_sum<256>(s, red);
     if (threadIdx.x == 0) hascf[r - N] = (s != 0.f) ? 1.f : 0.f;
   }
@@ -467,7 +490,14 @@ __global__ __launch_bounds__(256) void log_standardize_kernel(const float* __res
 
 int log_standardize(const float* X, const float* cfX, const float* log_mean, const float* log_scale, float* xn,
                     float* hascf, int N, int G, hipStream_t stream) {
-  hipLaunchKernelGGL(log_standardize_kernel, dim3(2 * N), dim3(256), 0, stream, X, cfX, log_mean, log_scale, xn, hascf, N, G);
+  const bool vec = G % 4 == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)cfX % 16 == 0) && ((uintptr_t)log_mean % 16 == 0) &&
+                   ((uintptr_t)log_scale % 16 == 0) && ((uintptr_t)xn % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL(log_standardize_kernel<true>, dim3(2 * N), dim3(256), 0, stream, X, cfX, log_mean, log_scale, xn, hascf,
+                       N, G);
+  else
+    hipLaunchKernelGGL(log_standardize_kernel<false>, dim3(2 * N), dim3(256), 0, stream, X, cfX, log_mean, log_scale, xn,
+                       hascf, N, G);
   CRADLE_CHECK_LAUNCH("log_standardize_kernel");
   return CRADLE_OK;
 }
@@ -481,6 +511,31 @@ int log_standardize(const float* X, const float* cfX, const float* log_mean, con
 // =====================================================================================
 __device__ __forceinline__ float sanitize(float v) { return finitef_(v) ? v : 0.f; }
 
+// V consecutive floats per lane (V = 4: one 16-byte access; V = 1: scalar fallback for odd widths or unaligned
+// pointers).  The row kernels below take V as a template parameter: with V = 4 a row of L <= 256 is one pass,
+// every load of a lane is issued before the first use, instead of up to four dependent passes of scalar loads.
+template <int V>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, float (&r)[V]) {
+  if constexpr (V == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < V; ++e) r[e] = p[e];
+  }
+}
+template <int V>
+__device__ __forceinline__ void stv(float* __restrict__ p, const float (&r)[V]) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < V; ++e) p[e] = r[e];
+  }
+}
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <int V>
 __global__ __launch_bounds__(256) void mask_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ u,
                                                        const float* __restrict__ p0, float tau, float* __restrict__ mask,
                                                        float* __restrict__ soft, float* __restrict__ S, int rows, int T, int Tc,
@@ -499,19 +554,28 @@ __global__ __launch_bounds__(256) void mask_fwd_kernel(const float* __restrict__
   }
   const float* urow = u + ((int64_t)pp * T + t) * L;
   float acc = 0.f;
-  for (int l = lane; l < L; l += 64) {
-    const float lg = sanitize(logits[t * L + l]);
-    const float p = clamp_probs(sigmoidf_(lg));
-    const float lq = logf(p) - log1pf(-p);
-    const float uu = clamp_probs(urow[l]);
-    const float y = (logf(uu) - log1pf(-uu) + lq) / tau;
-    const float s = clamp_probs(sigmoidf_(y));
-    const float m = rintf(s);
-    mask[(int64_t)row * L + l] = m;
-    soft[(int64_t)row * L + l] = s;
-    const float pp0 = p0[t * L + l];
-    const float lp = logf(pp0 / (1.0f - pp0));  // torch.logit
-    acc += (m * lp - softplusf_(lp)) - (m * lq - softplusf_(lq));
+  for (int l = lane * V; l < L; l += 64 * V) {
+    float lgv[V], uv[V], pv[V], mv[V], sv[V];
+    ldv<V>(logits + t * L + l, lgv);
+    ldv<V>(urow + l, uv);
+    ldv<V>(p0 + t * L + l, pv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float lg = sanitize(lgv[e]);
+      const float p = clamp_probs(sigmoidf_(lg));
+      const float lq = logf(p) - log1pf(-p);
+      const float uu = clamp_probs(uv[e]);
+      const float y = (logf(uu) - log1pf(-uu) + lq) / tau;
+      const float sft = clamp_probs(sigmoidf_(y));
+      const float m = rintf(sft);
+      mv[e] = m;
+      sv[e] = sft;
+      const float pp0 = pv[e];
+      const float lp = logf(pp0 / (1.0f - pp0));  // torch.logit
+      acc += (m * lp - softplusf_(lp)) - (m * lq - softplusf_(lq));
+    }
+    stv<V>(mask + (int64_t)row * L + l, mv);
+    stv<V>(soft + (int64_t)row * L + l, sv);
   }
   acc = wave_sum(acc);
   if (lane == 0) S[row] = acc;
@@ -520,8 +584,14 @@ __global__ __launch_bounds__(256) void mask_fwd_kernel(const float* __restrict__
 int mask_fwd(const float* logits, const float* u, const float* p_mask_probs, float tau, float* mask, float* soft,
              float* S, int PP, int T, int Tc, const int* tmap, int L, hipStream_t stream) {
   const int rows = PP * Tc;
-  hipLaunchKernelGGL(mask_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, u, p_mask_probs, tau, mask, soft,
-                     S, rows, T, Tc, tmap, L);
+  const bool vec = L % 4 == 0 && aligned16(logits) && aligned16(u) && aligned16(p_mask_probs) && aligned16(mask) &&
+                   aligned16(soft);
+  if (vec)
+    hipLaunchKernelGGL(mask_fwd_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, u, p_mask_probs, tau, mask,
+                       soft, S, rows, T, Tc, tmap, L);
+  else
+    hipLaunchKernelGGL(mask_fwd_kernel<1>, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, u, p_mask_probs, tau, mask,
+                       soft, S, rows, T, Tc, tmap, L);
   CRADLE_CHECK_LAUNCH("mask_fwd_kernel");
   return CRADLE_OK;
 }
@@ -808,6 +878,7 @@ int qce_bwd(const float* heads, const float* eps, const float* ploc, const float
 //   KL (loss_modules.py:145-151,190-196): on cells with cfX.sum != 0, with 1 = cf pass, 2 = q_z_cf_basal:
 //     beta * sum_l mean_p sum_n -0.5 (1 + lv1 - lv2 - (mu1-mu2)^2 - exp(lv1-lv2)),  lv = 2 log sd
 //   The KL branches have no other consumer, so their head gradients are written here already.
+template <int V>
 __global__ __launch_bounds__(256) void zhead_fwd_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
                                                         const float* __restrict__ hascf, float kl_coef, float* __restrict__ z,
                                                         int64_t ldz, float* __restrict__ sd, float* __restrict__ ltz,
@@ -821,31 +892,46 @@ __global__ __launch_bounds__(256) void zhead_fwd_kernel(const float* __restrict_
   const int64_t r1 = PN + r0, r2 = 2 * PN + r0;
   const bool cf = hascf[n] != 0.f;
   float a_lt = 0.f, a_kl = 0.f;
-  for (int l = lane; l < L; l += 64) {
-    const GaussVals g = gauss_vals(heads[r0 * 2 * L + l], heads[r0 * 2 * L + L + l]);
-    const float ep = eps[r0 * L + l];
-    const float zz = g.mean + g.sd * ep;
-    z[r0 * ldz + l] = zz;
-    sd[r0 * L + l] = g.sd;
-    a_lt += -0.5f * zz * zz + 0.5f * ep * ep + logf(g.sd);
-    float dm1 = 0.f, dv1 = 0.f, dm2 = 0.f, dv2 = 0.f;
+  for (int l = lane * V; l < L; l += 64 * V) {
+    float m0[V], v0[V], ep[V], m1[V], v1[V], m2[V], v2[V];
+    ldv<V>(heads + r0 * 2 * L + l, m0);
+    ldv<V>(heads + r0 * 2 * L + L + l, v0);
+    ldv<V>(eps + r0 * L + l, ep);
     if (cf) {
-      const GaussVals g2 = gauss_vals(heads[r1 * 2 * L + l], heads[r1 * 2 * L + L + l]);  // q_z_cf_basal
-      const GaussVals g1 = gauss_vals(heads[r2 * 2 * L + l], heads[r2 * 2 * L + L + l]);  // cf pass q_z_basal
-      const float lv1 = 2.0f * logf(g1.sd), lv2 = 2.0f * logf(g2.sd);
-      const float dmu = g1.mean - g2.mean;
-      const float ratio = expf(lv1 - lv2);
-      a_kl += -0.5f * (1.0f + lv1 - lv2 - dmu * dmu - ratio);
-      // d/d(mean), d/d(lv) then lv = log(exp(lv_raw) + 1e-4): d lv / d lv_raw = e / var
-      dm1 = g1.mean_ok ? kl_coef * dmu : 0.f;
-      dm2 = g2.mean_ok ? -kl_coef * dmu : 0.f;
-      dv1 = g1.var_ok ? kl_coef * (-0.5f) * (1.0f - ratio) * g1.e / (g1.sd * g1.sd) : 0.f;
-      dv2 = g2.var_ok ? kl_coef * (-0.5f) * (ratio - 1.0f) * g2.e / (g2.sd * g2.sd) : 0.f;
+      ldv<V>(heads + r1 * 2 * L + l, m2);  // q_z_cf_basal
+      ldv<V>(heads + r1 * 2 * L + L + l, v2);
+      ldv<V>(heads + r2 * 2 * L + l, m1);  // cf pass q_z_basal
+      ldv<V>(heads + r2 * 2 * L + L + l, v1);
     }
-    dheads[r1 * 2 * L + l] = dm2;
-    dheads[r1 * 2 * L + L + l] = dv2;
-    dheads[r2 * 2 * L + l] = dm1;
-    dheads[r2 * 2 * L + L + l] = dv1;
+    float zv[V], sdv[V], dm1[V], dv1[V], dm2[V], dv2[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const GaussVals g = gauss_vals(m0[e], v0[e]);
+      const float zz = g.mean + g.sd * ep[e];
+      zv[e] = zz;
+      sdv[e] = g.sd;
+      a_lt += -0.5f * zz * zz + 0.5f * ep[e] * ep[e] + logf(g.sd);
+      dm1[e] = dv1[e] = dm2[e] = dv2[e] = 0.f;
+      if (cf) {
+        const GaussVals g2 = gauss_vals(m2[e], v2[e]);
+        const GaussVals g1 = gauss_vals(m1[e], v1[e]);
+        const float lv1 = 2.0f * logf(g1.sd), lv2 = 2.0f * logf(g2.sd);
+        const float dmu = g1.mean - g2.mean;
+        const float ratio = expf(lv1 - lv2);
+        a_kl += -0.5f * (1.0f + lv1 - lv2 - dmu * dmu - ratio);
+        // d/d(mean), d/d(lv) then lv = log(exp(lv_raw) + 1e-4): d lv / d lv_raw = e / var
+        dm1[e] = g1.mean_ok ? kl_coef * dmu : 0.f;
+        dm2[e] = g2.mean_ok ? -kl_coef * dmu : 0.f;
+        dv1[e] = g1.var_ok ? kl_coef * (-0.5f) * (1.0f - ratio) * g1.e / (g1.sd * g1.sd) : 0.f;
+        dv2[e] = g2.var_ok ? kl_coef * (-0.5f) * (ratio - 1.0f) * g2.e / (g2.sd * g2.sd) : 0.f;
+      }
+    }
+    stv<V>(z + r0 * ldz + l, zv);
+    stv<V>(sd + r0 * L + l, sdv);
+    stv<V>(dheads + r1 * 2 * L + l, dm2);
+    stv<V>(dheads + r1 * 2 * L + L + l, dv2);
+    stv<V>(dheads + r2 * 2 * L + l, dm1);
+    stv<V>(dheads + r2 * 2 * L + L + l, dv1);
   }
   a_lt = wave_sum(a_lt);
   a_kl = wave_sum(a_kl);
@@ -858,8 +944,14 @@ __global__ __launch_bounds__(256) void zhead_fwd_kernel(const float* __restrict_
 int zhead_fwd(const float* heads, const float* eps, const float* hascf, float beta, float* z, int64_t ldz, float* sd,
               float* ltz, float* klrow, float* dheads, int P, int N, int L, hipStream_t stream) {
   const int64_t rows = (int64_t)P * N;
-  hipLaunchKernelGGL(zhead_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, heads, eps, hascf,
-                     beta / (float)P, z, ldz, sd, ltz, klrow, dheads, P, N, L);
+  const bool vec = L % 4 == 0 && ldz % 4 == 0 && aligned16(heads) && aligned16(eps) && aligned16(z) && aligned16(sd) &&
+                   aligned16(dheads);
+  if (vec)
+    hipLaunchKernelGGL(zhead_fwd_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, heads, eps, hascf,
+                       beta / (float)P, z, ldz, sd, ltz, klrow, dheads, P, N, L);
+  else
+    hipLaunchKernelGGL(zhead_fwd_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, heads, eps, hascf,
+                       beta / (float)P, z, ldz, sd, ltz, klrow, dheads, P, N, L);
   CRADLE_CHECK_LAUNCH("zhead_fwd_kernel");
   return CRADLE_OK;
 }
@@ -896,6 +988,7 @@ int zhead_bwd(const float* heads, const float* eps, const float* z, int64_t ldz,
 // Particles pp < P (main pass) go to offA (a column block of the decoder input [z | off]),
 // pp >= P (counterfactual pass) to offB.
 // =====================================================================================
+template <int V>
 __global__ __launch_bounds__(64) void gather_offsets_kernel(const float* __restrict__ heads, const float* __restrict__ eps,
                                                             const float* __restrict__ mask, const int* __restrict__ ell_idx,
                                                             const float* __restrict__ ell_val, int kmax, float* __restrict__ offA,
@@ -905,30 +998,48 @@ __global__ __launch_bounds__(64) void gather_offsets_kernel(const float* __restr
   // offA: the main pass once more, inside the decoder input [z | offset].
   // E[pp,t,l]*mask[pp,t,l] is evaluated here from the Gaussian heads for the <= kmax treatments of the
   // cell (same expression as gaussE_fwd_kernel: same bits), so the encoders do not wait for that kernel.
+  // No LDS: a cell reads <= kmax rows of 3L floats once, and the (2P*Tc, 3L) tables (2.5 MB at Norman) sit in L2.
   const int n = blockIdx.x, pp = blockIdx.y;
   float* out = offB + ((int64_t)pp * N + n) * ldB;
   float* out2 = pp < P ? offA + ((int64_t)pp * N + n) * ldA : nullptr;
-  for (int l = threadIdx.x; l < L; l += 64) {
-    float acc = 0.f;
+  for (int l = threadIdx.x * V; l < L; l += 64 * V) {
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
     for (int k = 0; k < kmax; ++k) {
       const int t = ell_idx[n * kmax + k];
       if (t < 0) break;
       const int slot = tpos ? tpos[t] : t;
       if (slot < 0) continue;
       const int64_t row = (int64_t)pp * Tc + slot;
-      const GaussVals g = gauss_vals(heads[row * 2 * L + l], heads[row * 2 * L + L + l]);
-      const float s = gauss_draw(g, eps[((int64_t)pp * T + t) * L + l]);
-      acc = fmaf(ell_val[n * kmax + k], s * mask[row * L + l], acc);
+      float mr[V], lv[V], ep[V], mk[V];
+      ldv<V>(heads + row * 2 * L + l, mr);
+      ldv<V>(heads + row * 2 * L + L + l, lv);
+      ldv<V>(eps + ((int64_t)pp * T + t) * L + l, ep);
+      ldv<V>(mask + row * L + l, mk);
+      const float dose = ell_val[n * kmax + k];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const GaussVals g = gauss_vals(mr[e], lv[e]);
+        const float sdraw = gauss_draw(g, ep[e]);
+        acc[e] = fmaf(dose, sdraw * mk[e], acc[e]);
+      }
     }
-    out[l] = acc;
-    if (out2) out2[l] = acc;
+    stv<V>(out + l, acc);
+    if (out2) stv<V>(out2 + l, acc);
   }
 }
 
 int gather_offsets(const float* heads, const float* eps, const float* mask, const DosagePlan& plan, float* offA, int64_t ldA,
                    float* offB, int64_t ldB, int PP, int P, int N, int T, int L, hipStream_t stream) {
-  hipLaunchKernelGGL(gather_offsets_kernel, dim3(N, PP), dim3(64), 0, stream, heads, eps, mask, plan.ell_idx, plan.ell_val,
-                     plan.kmax, offA, ldA, offB, ldB, P, N, T, plan.Tc, plan.tpos, L);
+  const bool vec = L % 4 == 0 && ldA % 4 == 0 && ldB % 4 == 0 && aligned16(heads) && aligned16(eps) && aligned16(mask) &&
+                   aligned16(offA) && aligned16(offB);
+  if (vec)
+    hipLaunchKernelGGL(gather_offsets_kernel<4>, dim3(N, PP), dim3(64), 0, stream, heads, eps, mask, plan.ell_idx,
+                       plan.ell_val, plan.kmax, offA, ldA, offB, ldB, P, N, T, plan.Tc, plan.tpos, L);
+  else
+    hipLaunchKernelGGL(gather_offsets_kernel<1>, dim3(N, PP), dim3(64), 0, stream, heads, eps, mask, plan.ell_idx,
+                       plan.ell_val, plan.kmax, offA, ldA, offB, ldB, P, N, T, plan.Tc, plan.tpos, L);
   CRADLE_CHECK_LAUNCH("gather_offsets_kernel");
   return CRADLE_OK;
 }
@@ -941,6 +1052,7 @@ int gather_offsets(const float* heads, const float* eps, const float* mask, cons
 //   v=0 main pass q_z_basal (s = qc), v=1 main pass q_z_cf_basal (s = 1-qc),
 //   v=2 counterfactual pass q_z_basal (x = cfX, particles P..2P-1, s = 1-qc)
 // =====================================================================================
+template <int V>
 __global__ __launch_bounds__(128) void enc_combine_fwd_kernel(const float* __restrict__ xW, const float* __restrict__ offW,
                                                               const float* __restrict__ vq, const float* __restrict__ bias,
                                                               const float* __restrict__ qc, float* __restrict__ h, int P,
@@ -950,42 +1062,67 @@ __global__ __launch_bounds__(128) void enc_combine_fwd_kernel(const float* __res
   const float* xr = xW + (int64_t)(v == 2 ? N + n : n) * H;
   const float* orow = offW + ((int64_t)pp * N + n) * H;
   float* out = h + (((int64_t)v * P + p) * N + n) * H;
-  for (int j = threadIdx.x; j < H; j += 128) {
-    float a = xr[j] + orow[j];
+  for (int j = threadIdx.x * V; j < H; j += 128 * V) {
+    float a[V], o[V], b[V];
+    ldv<V>(xr + j, a);
+    ldv<V>(orow + j, o);
+    ldv<V>(bias + j, b);
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] += o[e];
     for (int q = 0; q < Q; ++q) {
-      const float s = v == 0 ? qc[(int64_t)n * Q + q] : 1.0f - qc[(int64_t)n * Q + q];
-      a = fmaf(s, vq[((int64_t)pp * Q + q) * H + j], a);
+      const float sq = v == 0 ? qc[(int64_t)n * Q + q] : 1.0f - qc[(int64_t)n * Q + q];
+      float w[V];
+      ldv<V>(vq + ((int64_t)pp * Q + q) * H + j, w);
+#pragma unroll
+      for (int e = 0; e < V; ++e) a[e] = fmaf(sq, w[e], a[e]);
     }
-    a += bias[j];
-    out[j] = a > 0.f ? a : kLeakySlope * a;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      a[e] += b[e];
+      a[e] = a[e] > 0.f ? a[e] : kLeakySlope * a[e];
+    }
+    stv<V>(out + j, a);
   }
 }
 
 int enc_combine_fwd(const float* xW, const float* offW, const float* vq, const float* bias, const float* qc, float* h,
                     int P, int N, int Q, int H, hipStream_t stream) {
-  hipLaunchKernelGGL(enc_combine_fwd_kernel, dim3(N, P, 3), dim3(128), 0, stream, xW, offW, vq, bias, qc, h, P, N, Q, H);
+  const bool vec = H % 4 == 0 && aligned16(xW) && aligned16(offW) && aligned16(vq) && aligned16(bias) && aligned16(h);
+  if (vec)
+    hipLaunchKernelGGL(enc_combine_fwd_kernel<4>, dim3(N, P, 3), dim3(128), 0, stream, xW, offW, vq, bias, qc, h, P, N, Q, H);
+  else
+    hipLaunchKernelGGL(enc_combine_fwd_kernel<1>, dim3(N, P, 3), dim3(128), 0, stream, xW, offW, vq, bias, qc, h, P, N, Q, H);
   CRADLE_CHECK_LAUNCH("enc_combine_fwd_kernel");
   return CRADLE_OK;
 }
 
 // dpre (3PN, H) -> doffW (2P*N, H), dxW (2N, H)
+template <int V>
 __global__ __launch_bounds__(128) void enc_combine_bwd_kernel(const float* __restrict__ dpre, float* __restrict__ doffW,
                                                               float* __restrict__ dxW, int P, int N, int H) {
   const int n = blockIdx.x;
   const int64_t PN = (int64_t)P * N;
-  for (int j = threadIdx.x; j < H; j += 128) {
-    float sa = 0.f, sb = 0.f;
+  for (int j = threadIdx.x * V; j < H; j += 128 * V) {
+    float sa[V], sb[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) sa[e] = sb[e] = 0.f;
     for (int p = 0; p < P; ++p) {
       const int64_t r = (int64_t)p * N + n;
-      const float a = dpre[r * H + j] + dpre[(PN + r) * H + j];
-      const float b = dpre[(2 * PN + r) * H + j];
-      doffW[r * H + j] = a;
-      doffW[(PN + r) * H + j] = b;
-      sa += a;
-      sb += b;
+      float a[V], a2[V], b[V];
+      ldv<V>(dpre + r * H + j, a);
+      ldv<V>(dpre + (PN + r) * H + j, a2);
+      ldv<V>(dpre + (2 * PN + r) * H + j, b);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        a[e] += a2[e];
+        sa[e] += a[e];
+        sb[e] += b[e];
+      }
+      stv<V>(doffW + r * H + j, a);
+      stv<V>(doffW + (PN + r) * H + j, b);
     }
-    dxW[(int64_t)n * H + j] = sa;
-    dxW[(int64_t)(N + n) * H + j] = sb;
+    stv<V>(dxW + (int64_t)n * H + j, sa);
+    stv<V>(dxW + (int64_t)(N + n) * H + j, sb);
   }
 }
 
@@ -1024,7 +1161,12 @@ __global__ __launch_bounds__(256) void enc_combine_bwd_vq_kernel(const float* __
 // which: 1 = the (doffW, dxW) kernel on `stream`, 2 = the dvq kernel on `vq_stream`, 3 = both
 int enc_combine_bwd(const float* dpre, const float* qc, float* doffW, float* dxW, float* dvq, int P, int N, int Q, int H,
                     hipStream_t stream, hipStream_t vq_stream, int which) {
-  if (which & 1) hipLaunchKernelGGL(enc_combine_bwd_kernel, dim3(N), dim3(128), 0, stream, dpre, doffW, dxW, P, N, H);
+  if (which & 1) {
+    if (H % 4 == 0 && aligned16(dpre) && aligned16(doffW) && aligned16(dxW))
+      hipLaunchKernelGGL(enc_combine_bwd_kernel<4>, dim3(N), dim3(128), 0, stream, dpre, doffW, dxW, P, N, H);
+    else
+      hipLaunchKernelGGL(enc_combine_bwd_kernel<1>, dim3(N), dim3(128), 0, stream, dpre, doffW, dxW, P, N, H);
+  }
   if (which & 2)
     hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3((H + 15) / 16, 2 * P * Q), dim3(256), 0, vq_stream, dpre, qc, dvq,
                        P, N, Q, H);
