@@ -1126,35 +1126,84 @@ __global__ __launch_bounds__(128) void enc_combine_bwd_kernel(const float* __res
   }
 }
 
-// dvq[pp,q,:] = sum_n s_q[n] dpre[variant rows]; 16 columns x 64 cell slices per block
+// dvq[pp,q,:] = sum_n s_q[n] dpre[variant rows].  A workgroup owns 64 columns (16 lanes x float4 = one 256-byte
+// segment of every row) of one (pp, q); its 16 row slices walk the cells with independent 16-byte loads and meet
+// in LDS in a fixed order (deterministic).  VEC = false: the scalar form for H % 4 != 0 (16 columns per workgroup).
+template <bool VEC>
 __global__ __launch_bounds__(256) void enc_combine_bwd_vq_kernel(const float* __restrict__ dpre, const float* __restrict__ qc,
                                                                  float* __restrict__ dvq, int P, int N, int Q, int H) {
   constexpr int SL = 16;  // row slices per workgroup
-  __shared__ float part[SL][17];
+  constexpr int W = VEC ? 4 : 1;
+  __shared__ float part[SL][16 * W + 1];
   const int q = blockIdx.y % Q, pp = blockIdx.y / Q;
   const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int j = blockIdx.x * 16 + c;
+  const int j = (blockIdx.x * 16 + c) * W;
   const int64_t PN = (int64_t)P * N;
-  float acc = 0.f;
+  float acc[W];
+#pragma unroll
+  for (int e = 0; e < W; ++e) acc[e] = 0.f;
   if (j < H) {
-    for (int n = sl; n < N; n += SL) {
-      const float s = qc[(int64_t)n * Q + q];
-      if (pp < P) {
-        const int64_t r = (int64_t)pp * N + n;
-        acc += s * dpre[r * H + j] + (1.0f - s) * dpre[(PN + r) * H + j];
-      } else {
-        const int64_t r = 2 * PN + (int64_t)(pp - P) * N + n;
-        acc += (1.0f - s) * dpre[r * H + j];
+    if (pp < P) {
+      const float* a = dpre + ((int64_t)pp * N) * H + j;
+      const float* b = a + PN * H;
+      int n = sl;
+      for (; n + 3 * SL < N; n += 4 * SL) {  // four cells (eight rows) in flight
+        float va[4][W], vb[4][W], sq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ldv<W>(a + (int64_t)(n + i * SL) * H, va[i]);
+          ldv<W>(b + (int64_t)(n + i * SL) * H, vb[i]);
+          sq[i] = qc[(int64_t)(n + i * SL) * Q + q];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < W; ++e) acc[e] += sq[i] * va[i][e] + (1.0f - sq[i]) * vb[i][e];
+      }
+      for (; n < N; n += SL) {
+        float va[W], vb[W];
+        ldv<W>(a + (int64_t)n * H, va);
+        ldv<W>(b + (int64_t)n * H, vb);
+        const float sq = qc[(int64_t)n * Q + q];
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[e] += sq * va[e] + (1.0f - sq) * vb[e];
+      }
+    } else {
+      const float* a = dpre + (2 * PN + (int64_t)(pp - P) * N) * H + j;
+      int n = sl;
+      for (; n + 7 * SL < N; n += 8 * SL) {
+        float va[8][W], sq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          ldv<W>(a + (int64_t)(n + i * SL) * H, va[i]);
+          sq[i] = qc[(int64_t)(n + i * SL) * Q + q];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int e = 0; e < W; ++e) acc[e] += (1.0f - sq[i]) * va[i][e];
+      }
+      for (; n < N; n += SL) {
+        float va[W];
+        ldv<W>(a + (int64_t)n * H, va);
+        const float sq = qc[(int64_t)n * Q + q];
+#pragma unroll
+        for (int e = 0; e < W; ++e) acc[e] += (1.0f - sq) * va[e];
       }
     }
   }
-  part[sl][c] = acc;
+#pragma unroll
+  for (int e = 0; e < W; ++e) part[sl][c * W + e] = acc[e];
   __syncthreads();
   if (sl == 0 && j < H) {
-    float t = 0.f;
+    float t[W];
 #pragma unroll
-    for (int k = 0; k < SL; ++k) t += part[k][c];
-    dvq[((int64_t)pp * Q + q) * H + j] = t;
+    for (int e = 0; e < W; ++e) {
+      t[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < SL; ++k) t[e] += part[k][c * W + e];
+    }
+    stv<W>(dvq + ((int64_t)pp * Q + q) * H + j, t);
   }
 }
 
@@ -1167,9 +1216,14 @@ int enc_combine_bwd(const float* dpre, const float* qc, float* doffW, float* dxW
     else
       hipLaunchKernelGGL(enc_combine_bwd_kernel<1>, dim3(N), dim3(128), 0, stream, dpre, doffW, dxW, P, N, H);
   }
-  if (which & 2)
-    hipLaunchKernelGGL(enc_combine_bwd_vq_kernel, dim3((H + 15) / 16, 2 * P * Q), dim3(256), 0, vq_stream, dpre, qc, dvq,
-                       P, N, Q, H);
+  if (which & 2) {
+    if (H % 4 == 0 && aligned16(dpre) && aligned16(dvq))
+      hipLaunchKernelGGL(enc_combine_bwd_vq_kernel<true>, dim3((H / 4 + 15) / 16, 2 * P * Q), dim3(256), 0, vq_stream, dpre,
+                         qc, dvq, P, N, Q, H);
+    else
+      hipLaunchKernelGGL(enc_combine_bwd_vq_kernel<false>, dim3((H + 15) / 16, 2 * P * Q), dim3(256), 0, vq_stream, dpre,
+                         qc, dvq, P, N, Q, H);
+  }
   CRADLE_CHECK_LAUNCH("enc_combine_bwd");
   return CRADLE_OK;
 }
@@ -1228,8 +1282,16 @@ __global__ __launch_bounds__(256) void sum_groups_to_cols_kernel(const float* __
     float s = 0.f;
     if (t < T && h < H) {
       const int slot = tpos ? tpos[t] : t;
-      if (slot >= 0)
-        for (int g = 0; g < groups; ++g) s += da[((int64_t)g * Tc + slot) * H + h];
+      if (slot >= 0) {
+        const float* src = da + (int64_t)slot * H + h;
+        const int64_t gs = (int64_t)Tc * H;
+        int g = 0;
+        for (; g + 3 < groups; g += 4) {  // four loads in flight, summed in order
+          const float v0 = src[g * gs], v1 = src[(g + 1) * gs], v2 = src[(g + 2) * gs], v3 = src[(g + 3) * gs];
+          s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; g < groups; ++g) s += src[g * gs];
+      }
     }
     tile[i][tx] = s;
   }
@@ -1258,8 +1320,21 @@ __global__ __launch_bounds__(256) void weighted_rowgroup_sum_kernel(const float*
   const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + c;
   float acc = 0.f;
-  if (j < H)
-    for (int n = sl; n < N; n += SL) acc = fmaf(w[n], da[((int64_t)p * N + n) * H + j], acc);
+  if (j < H) {
+    const float* src = da + (int64_t)p * N * H + j;
+    int n = sl;
+    for (; n + 7 * SL < N; n += 8 * SL) {  // eight rows in flight, accumulated in order
+      float v[8], wn[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] = src[(int64_t)(n + i * SL) * H];
+        wn[i] = w[n + i * SL];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = fmaf(wn[i], v[i], acc);
+    }
+    for (; n < N; n += SL) acc = fmaf(w[n], src[(int64_t)n * H], acc);
+  }
   part[sl][c] = acc;
   __syncthreads();
   if (sl == 0 && j < H) {

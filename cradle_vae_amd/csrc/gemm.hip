@@ -471,6 +471,7 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
     splitk = (int)min((int64_t)16, (2048 + ntiles - 1) / ntiles);
     splitk = max(1, min(splitk, k_tiles / 16));
   }
+  if (p.splitk_hint > 0) splitk = min(p.splitk_hint, max(1, k_tiles / 2));
   if (g_tune_splitk > 0) splitk = g_tune_splitk;
   if (!workspace || (uintptr_t)workspace % 16 != 0) splitk = 1;
   p.slab = ((int64_t)p.M * Np + 3) & ~int64_t(3);

@@ -33,6 +33,7 @@ struct GemmParams {
   float* partial;
   int64_t slab;           // floats between the partial results of consecutive K splits (multiple of 4)
   int k_tiles_per_split;
+  int splitk_hint;        // > 0: use this K split instead of the heuristic's (caller knows what runs beside it)
 };
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_floats, hipStream_t stream);

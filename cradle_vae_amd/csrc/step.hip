@@ -34,6 +34,14 @@ namespace {
 // cross-stream waits included, without a profiler (tools/phase_sweep.py).  0 = run everything.
 int g_stop_after = 0;
 
+// CRADLE_PROBE=k (tools only): the event the caller passes as ev_gemm_begin is recorded at forward checkpoint k
+// instead of right before the decoder's output layer, so that (ev_gemm_end - ev_gemm_begin) measures, on the
+// GPU's own clock and in the steady state, the time from that checkpoint to the end of the output layer
+// (k = 0..6), or from backward checkpoint k = 10..16 to the point where all streams have joined.
+int probe_at() {
+  static const int v = getenv("CRADLE_PROBE") ? atoi(getenv("CRADLE_PROBE")) : 6;
+  return v;
+}
 int sched_flags() {
   static const int v = getenv("CRADLE_SCHED") ? atoi(getenv("CRADLE_SCHED")) : 0;
   return v;
@@ -503,6 +511,8 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   // stream 2: q(qc_E) -- a chain of ten launches on a handful of rows, the longest path to the join when anything
   //           else shares its stream -- and, last, the per-gene constants K1 reads.
   // stream 0 (caller's): the step's noise, q(M), q(E|M), gathers -- then joins both.
+#define PROBE(k) do { if (probe_at() == (k) && d.ev_gemm_begin) (void)hipEventRecord((hipEvent_t)d.ev_gemm_begin, s); } while (0)
+  PROBE(0);
   {
     hipEvent_t e = c.record(0);  // one record on the caller's stream for both forks
     c.wait(1, e);
@@ -511,7 +521,11 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   STEP(build_dosage_plan(d.D, N, T, w.plan, s1));
   hipEvent_t ev_plan = c.record(1);
   STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s1));
-  c.gemm(GEMM_NT, gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G), 1);  // x Wx^T, X and cfX
+  {
+    GemmParams p = gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G);  // x Wx^T, X and cfX
+    p.splitk_hint = 4;  // beside the embedding encoder's chain: 8 us less to the join than the stand-alone heuristic's 2
+    c.gemm(GEMM_NT, p, 1);
+  }
   hipEvent_t ev_xw = c.record(1);
   STEP(build_dosage_plan_csc(N, T, w.plan, s1));
   STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, Tc, w.plan.tmap,
@@ -546,6 +560,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   hipEvent_t ev_s2 = c.record(2);
 
   if (w.plan.tmap) c.wait(0, ev_plan);
+  PROBE(1);
   STEP(mask_fwd(d.q_mask_logits, nz_u, d.p_mask_probs, d.temperature, w.mask, w.soft, w.Smask, PP, T, Tc, w.plan.tmap,
                 L, s));
   if (w.plan.tmap)
@@ -565,6 +580,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   // (E, its scale and the log-ratio sums are needed by the loss only -- the gather below and the backward pass
   // draw the E they need from the heads themselves -- and are made on stream 2 after K1, at a fork that exists anyway)
   if (!w.plan.tmap) c.wait(0, ev_plan);
+  PROBE(2);
   STEP(gather_offsets(w.headsE, nz_E, w.mask, w.plan, w.zoff + L, 2 * L, w.offB, L, PP, P, N, T, L, s));  // D @ (mask*E)
   c.gemm(GEMM_NT, gp(w.offB, L, Wenc0 + G, ldenc, w.offW, He, 2 * PN, He, L));  // offsets . Woff^T, both passes
   c.wait(0, ev_xw);  // the encoders need x Wx^T and qc_E Wqc^T; the rest of both side streams is met at the decoder
@@ -573,16 +589,19 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   if (g_stop_after == 3) { c.after(0, 1); c.after(0, 2); return c.rc; }
 
   // basal encoder (three variants), z_basal, counterfactual KL
+  PROBE(3);
   STEP(enc_combine_fwd(w.xW, w.offW, w.vq, d.enc.b[0], d.qc, w.yz[0], P, N, Q, He, s));
   trunk_fwd(c, d.enc, 3 * PN, He, w.yz, w.rz);
   head_fwd(c, d.enc, 3 * PN, He, 2 * L, w.yz[d.enc.n_layers - 1], w.headsz);
   if (c.rc) return c.rc;
   if (g_stop_after == 4) { c.after(0, 1); c.after(0, 2); return c.rc; }
+  PROBE(4);
   STEP(zhead_fwd(w.headsz, nz_z, w.hascf, d.beta, w.zoff, 2 * L, w.sdz, w.ltz, w.klrow, w.dheadsz, P, N, L, s));
 
   // decoder, live variant per cell (per-cell weights: stream 1; bad-variant shift, gene constants: stream 2)
   c.after(0, 1);
   c.wait(0, ev_s2);
+  PROBE(5);
   {
     GemmParams p = gp(w.zoff, 2 * L, Wd0, 3 * L, w.yd[0], Hd, PN, Hd, 2 * L);
     p.bias = d.dec.b[0]; p.act = 1; p.rowbias = w.wq; p.ld_rb = Hd; p.rb_mode = 1; p.rb_n = N;
@@ -591,9 +610,9 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   }
   trunk_fwd(c, d.dec, PN, Hd, w.yd, w.rd);
   if (g_stop_after == 5) return c.rc;
-  if (d.ev_gemm_begin) (void)hipEventRecord((hipEvent_t)d.ev_gemm_begin, s);
+  PROBE(6);
   head_fwd(c, d.dec, PN, Hd, G, w.yd[d.dec.n_layers - 1], w.logits);
-  if (d.ev_gemm_end) (void)hipEventRecord((hipEvent_t)d.ev_gemm_end, s);
+  if (d.ev_gemm_end && probe_at() < 10) (void)hipEventRecord((hipEvent_t)d.ev_gemm_end, s);
   if (c.rc) return c.rc;
   if (g_stop_after == 6) return c.rc;
   }
@@ -625,10 +644,12 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   // The data-gradient chain runs on stream 0; the weight-gradient GEMMs are forked to the side streams at as few
   // events as possible (see head_trunk_bwd).  All streams are joined before returning.
   // decoder: logits now hold d loss / d logits
+  PROBE(10);
   hipEvent_t ev_dec = nullptr;
   const float* da0d = head_trunk_bwd(c, d.dec, d.d_dec, PN, Hd, G, w.logits, w.yd, w.rd, w.Gd, w.dad, 0, 1, 2, ev_k1,
                                      &ev_dec, d.ev_bucket[0]);
   if (c.rc) return c.rc;
+  PROBE(11);
   if (!ev_dec) ev_dec = c.record(0);
   c.wait(2, ev_dec);
   {  // dW0[:, :2L] = da0^T [z | off], db0
@@ -646,8 +667,10 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
 
   // basal encoder
   STEP(zhead_bwd(w.headsz, nz_z, w.zoff, 2 * L, w.sdz, w.dzoff, 2 * L, w.dheadsz, P, N, L, s));
+  PROBE(12);
   const float* dpre = head_trunk_bwd(c, d.enc, d.d_enc, 3 * PN, He, 2 * L, w.dheadsz, w.yz, w.rz, w.Gz, w.daz, 0, 1, 2);
   if (c.rc) return c.rc;
+  PROBE(13);
   STEP(enc_combine_bwd(dpre, d.qc, w.doffW, w.dxW, w.dvq, P, N, Q, He, s, s2, 1));
   float* dWenc0 = d.d_enc.W[0];
   {
@@ -680,28 +703,45 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   if (c.rc) return c.rc;
 
   // q(E|M), q(M)  (E and its scale are recomputed from the heads: stream 2's bookkeeping kernel is not waited for)
+  PROBE(14);
   STEP(gaussE_bwd(w.plan, w.dzoff + L, 2 * L, w.doffenc, L, w.doffenc + (int64_t)PN * L, L, w.headsE, nz_E, w.mask,
                   d.p_E_loc, d.p_E_scale, nullptr, nullptr, w.cp.coefTc, w.dheadsE, w.dmaskME, PP, P, N, T, L, s));
   hipEvent_t ev_emb = nullptr;
   // (the step's tail: nothing else is left to hide a late weight gradient behind, so these fork in twos)
-  const float* da0E = head_trunk_bwd(c, d.emb, d.d_emb, PT, Hm, 2 * L, w.dheadsE, w.yE, w.rE, w.GE, w.daE, 0, 1, 2, nullptr,
+  const float* da0E = head_trunk_bwd(c, d.emb, d.d_emb, PT, Hm, 2 * L, w.dheadsE, w.yE, w.rE, w.GE, w.daE, 0, 1, 1, nullptr,
                                      &ev_emb, nullptr, 2);
   if (c.rc) return c.rc;
+  PROBE(15);
+  constexpr int y3 = 3;  // bit 0: dW0[:, :L], bit 1: dW0[:, L:] -- on the caller's stream after its last kernel (measured: -16 us)
   if (!ev_emb) ev_emb = c.record(0);
   c.wait(1, ev_emb);
-  {  // dW0[:, :L] = da0^T mask, db0
+  auto emb_dW0 = [&](int q) {  // dW0[:, :L] = da0^T mask, db0
     GemmParams p = gp(da0E, Hm, w.mask, L, d.d_emb.W[0], L + T, Hm, L, PT);
     p.extra_col = d.d_emb.b[0];
-    c.gemm(GEMM_TN, p, 1);
-  }
-  STEP(sum_over_groups_to_cols(da0E, PP, T, Tc, w.plan.tpos, Hm, d.d_emb.W[0], L + T, L, s1));            // dW0[:, L:]
+    c.gemm(GEMM_TN, p, q);
+  };
+  if (!(y3 & 1)) emb_dW0(1);
+  if (!(y3 & 2)) STEP(sum_over_groups_to_cols(da0E, PP, T, Tc, w.plan.tpos, Hm, d.d_emb.W[0], L + T, L, s1));            // dW0[:, L:]
   c.gemm(GEMM_NN, gp(da0E, Hm, d.emb.W[0], L + T, w.dmask_enc, L, PT, L, Hm));            // d mask via encoder input
   if (c.rc) return c.rc;
   STEP(mask_bwd(d.q_mask_logits, d.p_mask_probs, d.temperature, w.mask, w.soft, w.dmaskME, w.dmask_enc, w.cp.coefT,
                 d.d_q_mask_logits, PP, P, T, Tc, w.plan.tpos, L, s));
-  c.after(0, 1);
-  c.after(0, 2);
+  // the caller's stream would only wait from here on: it takes the last leaves itself
+  if (y3 & 1) emb_dW0(0);
+  if (y3 & 2) STEP(sum_over_groups_to_cols(da0E, PP, T, Tc, w.plan.tpos, Hm, d.d_emb.W[0], L + T, L, s));
+  PROBE(16);
+  if (probe_at() == 17 || probe_at() == 18) {  // how long the caller's stream waits for stream 1 / stream 2 alone
+    if (d.ev_gemm_begin) (void)hipEventRecord((hipEvent_t)d.ev_gemm_begin, s);
+    c.after(0, probe_at() == 17 ? 1 : 2);
+    if (d.ev_gemm_end) (void)hipEventRecord((hipEvent_t)d.ev_gemm_end, s);
+    c.after(0, probe_at() == 17 ? 2 : 1);
+  } else {
+    c.after(0, 1);
+    c.after(0, 2);
+    if (d.ev_gemm_end && probe_at() >= 10) (void)hipEventRecord((hipEvent_t)d.ev_gemm_end, s);
+  }
   if (c.rc) return c.rc;
+#undef PROBE
 #undef STEP
   return CRADLE_OK;
 }
