@@ -184,14 +184,15 @@ def cpu_baseline(shape, seconds_budget=25.0, as_written=False):
     }
 
 
-def secondary_shape(name, device, args):
-    """The same step at the Replogle-like shape (north_star quotes both), measured after the main
-    region on the same device: side information, not the headline metric."""
+def secondary_shape(name, device, args, precision="f32"):
+    """The same step at another shape (north_star quotes the Replogle-like one too) or in the optional split-bf16
+    GEMM mode, measured after the main region on the same device: side information, not the headline metric."""
     from cradle_vae_amd import synthetic as syn
     from cradle_vae_amd.trainer import TrainStep
 
     shape = syn.SHAPES[name]
     lm, batch = build(shape, device, seed=1000)
+    lm.precision = precision
     st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=1)
     steps = max(10, min(args.steps, 50))
     for _ in range(5):
@@ -202,10 +203,15 @@ def secondary_shape(name, device, args):
         st(batch, n_particles=shape.n_particles)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"value": shape.n_cells / dt, "unit": "cells/s", "ms_per_step": dt * 1e3, "steps": steps,
-            "workload": f"{shape.name}: N={shape.n_cells}, P={shape.n_particles}, G={shape.n_phenos}, "
-                        f"T={shape.n_treatments} ({min(shape.n_treatments, shape.n_cells * lm.max_dosages_per_cell)} "
-                        f"treatment slots), L={shape.n_latent}"}
+    res = {"value": shape.n_cells / dt, "unit": "cells/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "workload": f"{shape.name}: N={shape.n_cells}, P={shape.n_particles}, G={shape.n_phenos}, "
+                       f"T={shape.n_treatments} ({min(shape.n_treatments, shape.n_cells * lm.max_dosages_per_cell)} "
+                       f"treatment slots), L={shape.n_latent}"}
+    if precision != "f32":
+        res["dtype"] = "bf16x3 (bf16 hi+lo operands, 3 products, fp32 accumulate) in the GEMMs of >= 1 GFLOP; f32 elsewhere"
+        if not args.no_cpu_baseline:
+            res["loss_rel_err_vs_oracle"], res["loss_terms_max_rel_err_vs_oracle"] = loss_parity(lm, shape, batch, device)
+    return res
 
 
 def trace(msg):
@@ -361,6 +367,8 @@ def main():
         }
         if world == 1 and args.shape == "norman" and not args.no_secondary:
             out["replogle_shape"] = secondary_shape("replogle", device, args)
+            # optional arithmetic mode, a side number: the headline above is fp32 (the reference's precision)
+            out["bf16x3"] = secondary_shape("norman", device, args, precision="bf16x3")
         if not args.no_cpu_baseline and world == 1:
             if stepper.fused is not None:
                 rel, rel_terms = loss_parity(lm, shape, batch, device)

@@ -16,6 +16,7 @@
 // 256 threads = 4 waves in a 2x2 arrangement; each wave owns TM x TN tiles of 32x32.
 #include "common.h"
 #include "kernels.h"
+#include "gemm_epilogue.h"
 
 namespace cradle {
 
@@ -118,93 +119,6 @@ struct TileLoader {
     }
   }
 };
-
-// The fused epilogue of NE output elements of one thread (shared by the GEMM kernel and the split-K reducer).
-// Every feature is handled for all NE elements at once -- its NE loads are issued back to back and waited
-// for once -- instead of element by element: with the features behind run-time branches, the element-wise
-// form serialises up to 3 dependent global-load latencies per element, 16 elements per lane, which was
-// most of the fixed cost of the small products.  Loads of elements outside the matrix go to a clamped
-// (valid) address; only the stores are guarded.  Per element the arithmetic is, in this order:
-//   v + bias[col] + (rowscale ? rowscale * rowbias : rowbias) -> LeakyReLU -> (act_out) -> + res -> + beta*C
-template <int NE>
-__device__ __forceinline__ void epilogue_batch(const GemmParams& p, const int (&row_in)[NE], const int (&col_in)[NE],
-                                               const bool (&ok)[NE], float (&v)[NE]) {
-  int row[NE], col[NE];
-  bool ones[NE];
-#pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    ones[e] = col_in[e] == p.N;  // virtual ones column -> bias gradient
-    row[e] = ok[e] ? row_in[e] : 0;
-    col[e] = ok[e] && !ones[e] ? col_in[e] : 0;
-  }
-  if (p.extra_col) {
-    float old[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) old[e] = (p.beta != 0.f && ones[e]) ? p.extra_col[row[e]] : 0.f;
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-      if (ok[e] && ones[e]) p.extra_col[row[e]] = v[e] + (p.beta != 0.f ? p.beta * old[e] : 0.f);
-  }
-  if (p.bias) {
-    float b[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) b[e] = p.bias[col[e]];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) v[e] += b[e];
-  }
-  if (p.rowbias) {
-    float rb[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int rb_row = p.rb_mode == 1 ? row[e] / p.rb_n : row[e] % p.rb_n;
-      rb[e] = p.rowbias[(int64_t)rb_row * p.ld_rb + col[e]];
-    }
-    if (p.rowscale) {
-      float rs[NE];
-#pragma unroll
-      for (int e = 0; e < NE; ++e) rs[e] = p.rowscale[row[e] % p.rs_n];
-#pragma unroll
-      for (int e = 0; e < NE; ++e) v[e] += rs[e] * rb[e];
-    } else {
-#pragma unroll
-      for (int e = 0; e < NE; ++e) v[e] += rb[e];
-    }
-  }
-  if (p.act) {
-#pragma unroll
-    for (int e = 0; e < NE; ++e) v[e] = v[e] > 0.f ? v[e] : kLeakySlope * v[e];
-  }
-  if (p.act_out) {
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-      if (ok[e] && !ones[e]) p.act_out[(int64_t)row[e] * p.ld_act + col[e]] = v[e];
-  }
-  if (p.res) {
-    float r[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) r[e] = p.res[(int64_t)row[e] * p.ld_res + col[e]];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) v[e] += r[e];
-  }
-  if (p.beta != 0.f) {
-    float c[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) c[e] = p.C[(int64_t)row[e] * p.ldc + col[e]];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) v[e] += p.beta * c[e];
-  }
-#pragma unroll
-  for (int e = 0; e < NE; ++e)
-    if (ok[e] && !ones[e]) p.C[(int64_t)row[e] * p.ldc + col[e]] = v[e];
-  if (p.C2) {
-    float d[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) d[e] = p.dact_src[(int64_t)row[e] * p.ld_ds + col[e]];
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-      if (ok[e] && !ones[e]) p.C2[(int64_t)row[e] * p.ldc2 + col[e]] = v[e] * (d[e] > 0.f ? 1.f : kLeakySlope);
-  }
-}
 
 // WK = 2: eight waves per workgroup; waves 4-7 take the second half of every K step of the same
 // 2x2 arrangement of 32x32 tiles, so each SIMD holds two waves whose LDS round trips
@@ -491,6 +405,32 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
   if (layout == 0) aligned = aligned && p.K % 4 == 0;
   else if (layout == 1) aligned = aligned && p.K % 4 == 0 && p.N % 4 == 0 && p.N >= 4;
   else aligned = aligned && p.M % 4 == 0 && p.N % 4 == 0 && p.M >= 4 && p.N >= 4;
+  if (p.precision == 1 && aligned && flops >= 1.0e9) {
+    // split-bf16 kernels: 128 x 128 tiles, 64 in a dimension that pads less that way (400 -> 448 instead of 512);
+    // two to four workgroups per CU, so aim at ~1024 of them (tools/bench_bf16x3.py), never below 8 K-steps per split
+    auto padded = [](int n, int t) { return (n + 64 * t - 1) / (64 * t) * (64 * t); };
+    const int tm3 = padded(p.M, 2) <= padded(p.M, 1) ? 2 : 1, tn3 = padded(Np, 2) <= padded(Np, 1) ? 2 : 1;
+    const int64_t nt3 = (int64_t)(padded(p.M, tm3) / (64 * tm3)) * (padded(Np, tn3) / (64 * tn3));
+    const int kt3 = (p.K + 31) / 32;
+    int sk = 1;
+    if (workspace && (uintptr_t)workspace % 16 == 0 && nt3 < 768) {
+      sk = (int)min((int64_t)16, (1024 + nt3 - 1) / nt3);
+      sk = max(1, min(sk, kt3 / 8));
+    }
+    if (p.splitk_hint > 0 && workspace) sk = max(1, min(p.splitk_hint, kt3 / 2));
+    if (g_tune_splitk > 0 && workspace) sk = g_tune_splitk;
+    while (sk > 1 && (int64_t)sk * p.slab > workspace_floats) --sk;
+    p.k_tiles_per_split = (kt3 + sk - 1) / sk;
+    p.splitk = (kt3 + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
+    CRADLE_CHECK_ARG(launch_gemm_bf16x3(layout, p, tm3, tn3, stream), "gemm: no split-bf16 kernel for tile %dx%d", tm3, tn3);
+    CRADLE_CHECK_LAUNCH("gemm_bf16x3_kernel");
+    if (p.splitk > 1) {
+      const int64_t quads = (p.slab + 3) / 4;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
+      CRADLE_CHECK_LAUNCH("splitk_reduce_kernel");
+    }
+    return CRADLE_OK;
+  }
   dim3 grid((unsigned)ntiles, 1, (unsigned)splitk);
   bool ok;
   if (layout == 0) ok = launch_cfg<true, true>(p, ws, tm, tn, bk, depth, wk, aligned, grid, stream);
@@ -530,6 +470,8 @@ int cradle_gemm_f32(const cradle_gemm_desc* d, float* workspace, int64_t workspa
   p.act = d->act; p.act_out = d->act_out; p.ld_act = d->ld_act_out;
   p.res = d->residual; p.ld_res = d->ld_residual; p.dact_src = d->dact_src; p.ld_ds = d->ld_dact_src;
   p.C2 = d->C2; p.ldc2 = d->ldc2; p.extra_col = d->extra_col;
+  CRADLE_CHECK_ARG(d->precision == 0 || d->precision == 1, "gemm: precision must be 0 (fp32) or 1 (bf16x3), got %d", d->precision);
+  p.precision = d->precision;
   CRADLE_CHECK_ARG(!p.C2 || p.dact_src, "gemm: C2 needs dact_src");
   CRADLE_CHECK_ARG(!p.rowbias || ((p.rb_mode == 1 || p.rb_mode == 2) && p.rb_n > 0), "gemm: bad rowbias mode");
   CRADLE_CHECK_ARG(!p.rowscale || (p.rowbias && p.rs_n > 0), "gemm: rowscale needs rowbias");

@@ -34,10 +34,12 @@ struct GemmParams {
   int64_t slab;           // floats between the partial results of consecutive K splits (multiple of 4)
   int k_tiles_per_split;
   int splitk_hint;        // > 0: use this K split instead of the heuristic's (caller knows what runs beside it)
+  int precision;          // 0: fp32 MFMA (default); 1: split-bf16 (3 products) for products large enough to gain
 };
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_floats, hipStream_t stream);
 int64_t gemm_workspace_floats(int layout, int M, int N, int K, int extra_col);
+bool launch_gemm_bf16x3(int layout, const GemmParams& p, int tm, int tn, hipStream_t s);  // gemm_bf16x3.hip
 
 // ---- nb_loss.hip (C ABI entry points, see include/cradle_hip.h)
 }  // namespace cradle

@@ -249,8 +249,10 @@ struct Ctx {
   int rc = 0;
   hipStream_t s() const { return st[0]; }
   // C[M,N] = A . B(^T) with epilogue options set by the caller in p, on stream q
+  int precision = 0;
   void gemm(int layout, GemmParams p, int q = 0) {
     if (rc) return;
+    p.precision = precision;
     rc = gemm_f32(layout, p, splitk[q], kSplitKFloats, st[q]);
   }
   // everything enqueued on stream `dst` from now on waits for what `src` holds so far
@@ -439,6 +441,8 @@ int check_desc(const cradle_step_desc& d) {
   CRADLE_CHECK_ARG((uintptr_t)d.workspace % 256 == 0, "elbo_step: workspace must be 256-byte aligned");
   CRADLE_CHECK_ARG((uintptr_t)d.X % 16 == 0, "elbo_step: X must be 16-byte aligned");
   CRADLE_CHECK_ARG(d.temperature > 0.f, "elbo_step: temperature must be positive");
+  CRADLE_CHECK_ARG(d.precision == 0 || d.precision == 1, "elbo_step: precision must be 0 (fp32) or 1 (bf16x3), got %d",
+                   d.precision);
   return CRADLE_OK;
 }
 
@@ -760,6 +764,7 @@ int prepare(const cradle_step_desc* dp, Work& w, Ctx& c, hipStream_t main) {
   c.st[0] = main; c.st[1] = ss->side[0]; c.st[2] = ss->side[1];
   if (sched_flags() & 2) c.st[1] = c.st[2] = main;
   c.marker = ss->marker;
+  c.precision = d.precision;
   for (int i = 0; i < 3; ++i) c.splitk[i] = w.splitk[i];
   c.ev = ss->ev;
   return CRADLE_OK;

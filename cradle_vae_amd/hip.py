@@ -93,7 +93,7 @@ PROTOTYPES = {
 }
 
 MAX_LAYERS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MlpPtrs(ctypes.Structure):
@@ -125,7 +125,8 @@ class StepDesc(ctypes.Structure):
         + [("out", ctypes.c_void_p), ("flags", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
            ("workspace_bytes", i64), ("ev_k1_begin", ctypes.c_void_p), ("ev_k1_end", ctypes.c_void_p),
            ("ev_gemm_begin", ctypes.c_void_p), ("ev_gemm_end", ctypes.c_void_p), ("ev_bucket", ctypes.c_void_p * 3),
-           ("rng_seed_plated", ctypes.c_uint64), ("rng_seed_local", ctypes.c_uint64), ("rng_step", ctypes.c_uint64)]
+           ("rng_seed_plated", ctypes.c_uint64), ("rng_seed_local", ctypes.c_uint64), ("rng_step", ctypes.c_uint64),
+           ("precision", i32)]
     )
 
 
@@ -147,6 +148,7 @@ class GemmDesc(ctypes.Structure):
         ("dact_src", ctypes.c_void_p), ("ld_dact_src", i64),
         ("C2", ctypes.c_void_p), ("ldc2", i64),
         ("extra_col", ctypes.c_void_p),
+        ("precision", i32),
     ]
 
 

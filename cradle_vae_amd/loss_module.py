@@ -46,6 +46,9 @@ class PerturbationPlatedELBOLossModule(torch.nn.Module):
         self.alpha = alpha
         self.beta = beta
         self.step = "auto"  # 'auto' | 'fused' | 'modular'
+        # GEMM arithmetic of the fused step: 'f32' (exact fp32 MFMA, the reference's precision: default) or 'bf16x3'
+        # (split-bf16, three bf16 products per element pair with fp32 accumulation, for the step's large products)
+        self.precision = "f32"
         # upper bound of non-zero dosages per cell the fused step plans for (its kmax); data sets know the
         # true value (data.TensorPerturbationDataset.max_dosages_per_cell), trainer.fit copies it here
         self.max_dosages_per_cell = 8

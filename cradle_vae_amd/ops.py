@@ -202,16 +202,20 @@ def _mat(t: torch.Tensor):
     return t.data_ptr(), t.stride(0)
 
 
+PRECISIONS = {"f32": 0, "bf16x3": 1}
+
+
 def gemm(
     layout: int, A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, *, beta: float = 0.0,
     bias: Optional[torch.Tensor] = None, act: bool = False, act_out: Optional[torch.Tensor] = None,
     residual: Optional[torch.Tensor] = None, dact_src: Optional[torch.Tensor] = None,
     out2: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None, rowbias_mode: int = 0,
     rowbias_n: int = 0, rowscale: Optional[torch.Tensor] = None, extra_col: Optional[torch.Tensor] = None,
-    workspace: Optional[torch.Tensor] = None, repeat: int = 1,
+    workspace: Optional[torch.Tensor] = None, repeat: int = 1, precision: str = "f32",
 ) -> torch.Tensor:
     """fp32 MFMA GEMM with the fused epilogue of ``cradle_gemm_f32`` (see the header).
-    ``repeat`` > 1 relaunches the same GEMM from C (benchmarking aid)."""
+    ``repeat`` > 1 relaunches the same GEMM from C (benchmarking aid).  ``precision``: "f32" (exact fp32 MFMA) or
+    "bf16x3" (split-bf16, three products per element pair, for products of >= 1 GFLOP)."""
     if layout == NT:
         (M, K), (N, K2) = A.shape, B.shape
     elif layout == NN:
@@ -230,6 +234,7 @@ def gemm(
     d.B, d.ldb = _mat(B)
     d.C, d.ldc = _mat(out)
     d.beta, d.act = beta, int(act)
+    d.precision = PRECISIONS[precision]
     d.bias = hip.ptr(bias)
     if rowbias is not None:
         d.rowbias, d.ld_rowbias = _mat(rowbias)

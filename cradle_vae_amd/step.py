@@ -266,6 +266,7 @@ class FusedElboStep:
         d.beta = float(self.lm.beta)
         d.alpha = -1.0 if self.lm.alpha is None else float(self.lm.alpha)
         d.compute_grads = int(compute_grads)
+        d.precision = {"f32": 0, "bf16x3": 1}[getattr(self.lm, "precision", "f32")]
         sample = self._calls % max(1, self.event_every) == 0
         if self.k1_events is not None and sample:
             ev = hip.EventPair()

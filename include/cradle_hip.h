@@ -132,6 +132,11 @@ typedef struct cradle_gemm_desc {
   const float* dact_src; int64_t ld_dact_src;
   float* C2; int64_t ldc2;
   float* extra_col;
+  int precision;   /* 0: fp32 MFMA (exact fp32, the reference's arithmetic: default).  1: "bf16x3" -- operands split
+                      into bf16 hi + lo when a tile is staged, a_hi b_hi + a_hi b_lo + a_lo b_hi on
+                      v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~1e-6..1e-5 relative per dot product), used for
+                      products of >= 1 GFLOP with 16-byte aligned operands, fp32 otherwise.  Optional mode, no
+                      counterpart in the reference (which computes in fp32). */
 } cradle_gemm_desc;
 
 /* workspace (optional, may be NULL): lets small-output / long-K problems split along K. */
@@ -239,6 +244,7 @@ typedef struct cradle_step_desc {
                              [2] basal-encoder gradients (d_enc.*); the rest is final with the step.
                              NULL = off */
   uint64_t rng_seed_plated, rng_seed_local, rng_step;   /* used when the noise pointers are NULL */
+  int precision;          /* cradle_gemm_desc.precision for the step's GEMMs: 0 = fp32 (default), 1 = bf16x3 */
 } cradle_step_desc;
 
 int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only the sizes are read */

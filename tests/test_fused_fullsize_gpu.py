@@ -50,19 +50,36 @@ def test_fused_step_matches_oracle_at_full_size(name, kmax, seed):
 
     dev = lambda d: {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in d.items()}
     case = dict(cfg=cfg, params=dev(params), batch=dev(b), noise=dev(noise), cf_noise=dev(cf_noise))
-    lm = build_loss_module(case)
-    lm.max_dosages_per_cell = kmax
-    loss, metrics, grads = run_fused(lm, case)
-    d = lm._fused.desc
-    assert (d.N * d.kmax < d.T) == (name == "replogle")  # Replogle runs the compact treatment axis
+    # "f32": the product path.  "bf16x3": the optional split-bf16 mode of the step's large GEMMs (>= 1 GFLOP: the
+    # output layer's three products, x Wx^T and its weight gradient, the encoder heads').  Same 1e-4 bar for the loss
+    # and its terms (measured: the fp32 value to the last bit -- the ~1e-6 errors of 2.5 M logits average out below
+    # one ulp).  Gradients: a dot product is ~1e-6 off instead of ~1e-7, and x Wx^T feeds the encoder's first
+    # LeakyReLU directly: of its 3 M inputs the few hundred within ~1e-4 of zero land on the other side of the kink
+    # than in fp64 (see the module docstring for what one such flip does).  Measured over both shapes: relative L2
+    # 1.3e-4 .. 1.0e-3 per tensor, largest single entry 1e-2 of the tensor's maximum (encoder first layer,
+    # q_mask_logits) -- against 2e-7 .. 4e-6 for fp32.  Bars for this mode: 2e-2 max-scaled, 1e-2 relative L2.
+    worst = {}
+    for precision, l2_bar in (("f32", 2e-5), ("bf16x3", 1e-2)):
+        lm = build_loss_module(case)
+        lm.max_dosages_per_cell = kmax
+        lm.precision = precision
+        loss, metrics, grads = run_fused(lm, case)
+        d = lm._fused.desc
+        assert (d.N * d.kmax < d.T) == (name == "replogle")  # Replogle runs the compact treatment axis
+        assert d.precision == (1 if precision == "bf16x3" else 0)
 
-    rtol = 1e-4
-    assert abs(float(loss.detach()) - float(ref_loss)) <= rtol * abs(float(ref_loss)), (float(loss), float(ref_loss))
-    for k, v in ref_metrics.items():
-        assert abs(float(metrics[k]) - float(v)) <= rtol * max(1.0, abs(float(v))), (k, float(metrics[k]), float(v))
-    for k, g in ref_grads.items():
-        got = grads[k].detach().cpu().double()
-        err = float((got - g).abs().max()) / max(float(g.abs().max()), 1e-12)
-        assert err <= 2e-3, (k, err)
-        l2 = float((got - g).norm()) / max(float(g.norm()), 1e-12)
-        assert l2 <= 2e-5, (k, l2)
+        rtol = 1e-4
+        assert abs(float(loss.detach()) - float(ref_loss)) <= rtol * abs(float(ref_loss)), (precision, float(loss), float(ref_loss))
+        for k, v in ref_metrics.items():
+            assert abs(float(metrics[k]) - float(v)) <= rtol * max(1.0, abs(float(v))), (precision, k, float(metrics[k]), float(v))
+        worst[precision] = 0.0
+        for k, g in ref_grads.items():
+            got = grads[k].detach().cpu().double()
+            err = float((got - g).abs().max()) / max(float(g.abs().max()), 1e-12)
+            l2 = float((got - g).norm()) / max(float(g.norm()), 1e-12)
+            assert err <= (2e-3 if precision == "f32" else 2e-2), (precision, k, err)
+            assert l2 <= l2_bar, (precision, k, l2)
+            worst[precision] = max(worst[precision], l2)
+        worst[precision + "_loss"] = abs(float(loss.detach()) - float(ref_loss)) / abs(float(ref_loss))
+    print(f"\n{name}: worst relative L2 gradient error / loss error per precision: {worst}")
+    assert worst["bf16x3"] > worst["f32"]  # the mode was really taken

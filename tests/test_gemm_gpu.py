@@ -121,3 +121,66 @@ def test_every_kernel_configuration_all_layouts(cfg):
                 assert err <= 2e-7 * (K ** 0.5) * float(ref.abs().max()) + 1e-6, (cfg, layout, sk, err)
     finally:
         lib.cradle_gemm_tune(-1, -1, -1, -1, -1, -1)
+
+
+# ---- optional split-bf16 mode (precision="bf16x3"): same entry point, same epilogues, products >= 1 GFLOP
+def _close_b3(got, ref, K):
+    # per product ~3 * 2^-18 relative to |a||b| (dropped lo*lo term + two split residuals), random sign: the error of a
+    # length-K dot product of N(0,1) operands is ~1.2e-5 * sqrt(K) at worst; the bar leaves a factor of ~3 over what is seen
+    tol = 1.2e-5 * max(1.0, K ** 0.5) * max(1.0, float(ref.abs().max()) / max(1.0, K ** 0.5))
+    err = float((got.double().cpu() - ref.cpu()).abs().max())
+    rel = float((got.double().cpu() - ref.cpu()).norm() / ref.cpu().norm())
+    assert err < tol, (err, tol)
+    assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("M,N,K", [(2560, 5000, 400), (1024, 400, 5000), (7680, 400, 400), (2500, 4996, 120), (130, 4100, 1000)])
+def test_bf16x3_nt_bias_act_residual(M, N, K):
+    from cradle_vae_amd import hip, ops
+
+    x, W, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3), _rand(M, N, seed=4)
+    act_out = torch.empty(M, N, device=DEV)
+    ws = torch.empty(hip.load().cradle_gemm_workspace_floats(ops.NT, M, N, K, 0), device=DEV)
+    y = ops.gemm(ops.NT, x, W, bias=b, act=True, act_out=act_out, residual=r, workspace=ws, precision="bf16x3")
+    pre = torch.nn.functional.leaky_relu(x.double() @ W.double().T + b.double(), 0.01)
+    _close_b3(act_out, pre, K)
+    _close_b3(y, pre + r.double(), K)
+    y32 = ops.gemm(ops.NT, x, W, bias=b, act=True, residual=r)
+    assert not torch.equal(y, y32)  # the mode was really taken
+
+
+@pytest.mark.parametrize("M,N,K", [(2560, 400, 5000), (7680, 400, 400), (2500, 404, 1236)])
+def test_bf16x3_nn_dgrad_with_leaky_backward(M, N, K):
+    from cradle_vae_amd import hip, ops
+
+    dy, W, res, src = _rand(M, K, seed=1), _rand(K, N, seed=2), _rand(M, N, seed=3), _rand(M, N, seed=4)
+    out2 = torch.empty(M, N, device=DEV)
+    ws = torch.empty(hip.load().cradle_gemm_workspace_floats(ops.NN, M, N, K, 0), device=DEV)
+    dx = ops.gemm(ops.NN, dy, W, residual=res, dact_src=src, out2=out2, workspace=ws, precision="bf16x3")
+    ref = dy.double() @ W.double() + res.double()
+    _close_b3(dx, ref, K)
+    _close_b3(out2, ref * torch.where(src.double() > 0, 1.0, 0.01), K)
+
+
+@pytest.mark.parametrize("M,N,K,ws", [(5000, 400, 2560, True), (400, 5000, 1024, True), (400, 400, 7680, True),
+                                      (5000, 400, 2560, False), (404, 1236, 2500, True)])
+def test_bf16x3_tn_wgrad_bias_column_splitk(M, N, K, ws):
+    from cradle_vae_amd import hip, ops
+
+    dy, x = _rand(K, M, seed=1), _rand(K, N, seed=2)
+    db = torch.empty(M, device=DEV)
+    workspace = None
+    if ws:
+        workspace = torch.empty(hip.load().cradle_gemm_workspace_floats(ops.TN, M, N, K, 1), device=DEV)
+    dW = ops.gemm(ops.TN, dy, x, extra_col=db, workspace=workspace, precision="bf16x3")
+    _close_b3(dW, dy.double().T @ x.double(), K)
+    _close_b3(db, dy.double().sum(0), K)
+
+
+def test_bf16x3_small_or_unaligned_products_stay_fp32():
+    from cradle_vae_amd import ops
+
+    x, W = _rand(300, 402, seed=1), _rand(200, 402, seed=2)  # K % 4 != 0 and far below 1 GFLOP
+    assert torch.equal(ops.gemm(ops.NT, x, W, precision="bf16x3"), ops.gemm(ops.NT, x, W))
+    with pytest.raises(KeyError):
+        ops.gemm(ops.NT, x, W, precision="fp8")
