@@ -409,7 +409,8 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
     // split-bf16 kernels: 128 x 128 tiles, 64 in a dimension that pads less that way (400 -> 448 instead of 512);
     // two to four workgroups per CU, so aim at ~1024 of them (tools/bench_bf16x3.py), never below 8 K-steps per split
     auto padded = [](int n, int t) { return (n + 64 * t - 1) / (64 * t) * (64 * t); };
-    const int tm3 = padded(p.M, 2) <= padded(p.M, 1) ? 2 : 1, tn3 = padded(Np, 2) <= padded(Np, 1) ? 2 : 1;
+    int tm3 = padded(p.M, 2) <= padded(p.M, 1) ? 2 : 1, tn3 = padded(Np, 2) <= padded(Np, 1) ? 2 : 1;
+    if (g_tune_tm > 0) { tm3 = min(g_tune_tm, 2); tn3 = min(g_tune_tn, 2); }
     const int64_t nt3 = (int64_t)(padded(p.M, tm3) / (64 * tm3)) * (padded(Np, tn3) / (64 * tn3));
     const int kt3 = (p.K + 31) / 32;
     int sk = 1;
