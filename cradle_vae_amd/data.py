@@ -167,8 +167,10 @@ class DeviceBatchLoader:
 
     def __init__(self, dataset: TensorPerturbationDataset, batch_size: int, shuffle: bool = False,
                  drop_last: bool = False, seed: int = 0, rank: int = 0, world_size: int = 1, device=None,
-                 shard_storage: Optional[bool] = None, count_dtype="auto", sparse_dosage: bool = True):
+                 shard_storage: Optional[bool] = None, count_dtype="auto", sparse_dosage: bool = True,
+                 prefetch: bool = True):
         self.dataset = dataset
+        self.prefetch, self._side = prefetch, None
         self.batch_size, self.shuffle, self.drop_last = batch_size, shuffle, drop_last
         self.seed, self.rank, self.world_size = seed, rank, world_size
         self.device = torch.device(device) if device is not None else dataset.X.device
@@ -240,7 +242,8 @@ class DeviceBatchLoader:
         pos_dev = pos_all.to(self.device)
         n = len(pos_all)
         stop = n - n % self.batch_size if self.drop_last else n
-        for s in range(0, stop, self.batch_size):
+
+        def gather(s):
             sl = pos_dev[s:s + self.batch_size]
             batch = {}
             for k, v in self._t.items():
@@ -250,7 +253,37 @@ class DeviceBatchLoader:
                     r = v.index_select(0, sl)
                     batch[k] = r if r.dtype == torch.float32 else r.to(torch.float32)
             batch["idx"] = idx_all[s:s + self.batch_size]
-            yield batch
+            return batch
+
+        starts = list(range(0, stop, self.batch_size))
+        if self.device.type != "cuda" or not self.prefetch or not starts:
+            for s in starts:
+                yield gather(s)
+        else:
+            # the gathers of batch i+1 (index_select, integer -> fp32, densified D: ~0.1 ms of small kernels) run on a
+            # side stream while the consumer's stream works on batch i; the hand-over is one event per batch
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            side = self._side
+            side.wait_stream(torch.cuda.current_stream(self.device))  # storage and pos_dev were made there
+
+            def launch(s):
+                with torch.cuda.stream(side):
+                    b = gather(s)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                return b, ev
+
+            nxt = launch(starts[0])
+            for i in range(len(starts)):
+                batch, ev = nxt
+                nxt = launch(starts[i + 1]) if i + 1 < len(starts) else None
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                for t in batch.values():
+                    if t.is_cuda:
+                        t.record_stream(cur)  # allocated on the side stream, read on the consumer's
+                yield batch
         if self.shuffle:
             self.epoch += 1
 
