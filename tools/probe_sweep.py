@@ -2,13 +2,14 @@
 checkpoint with CRADLE_PROBE=k (csrc/step.hip), which moves the event pair bench.py reads as `largest_gemm.launch_us`
 to [checkpoint k, end of the output layer] (forward, k = 0..6) or [checkpoint k, all streams joined] (backward,
 k = 10..16; 17 / 18: how long the caller's stream waits for side stream 1 / 2 after its own last kernel).
-python tools/probe_sweep.py [steps]"""
+python tools/probe_sweep.py [steps] [shape]"""
 import json
 import os
 import subprocess
 import sys
 
 steps = sys.argv[1] if len(sys.argv) > 1 else "200"
+shape = sys.argv[2] if len(sys.argv) > 2 else "norman"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 names = {0: "step start", 1: "noise drawn, forks made", 2: "q(M) sample + embedding encoder done", 3: "gather + offset GEMM done, x Wx^T and qc_E Wqc^T met",
          4: "encoder first layer combine + heads GEMM done", 5: "z head done, side streams met", 6: "decoder hidden layers done (output layer starts)",
@@ -18,7 +19,7 @@ names = {0: "step start", 1: "noise drawn, forks made", 2: "q(M) sample + embedd
 res = {}
 for k in list(range(0, 7)) + list(range(10, 19)):
     env = dict(os.environ, CRADLE_PROBE=str(k))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", steps, "--warmup", "20", "--no-cpu-baseline", "--no-secondary"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", steps, "--warmup", "20", "--no-cpu-baseline", "--no-secondary", "--shape", shape],
                          env=env, capture_output=True, text=True, timeout=300)
     d = json.loads(out.stdout.strip().splitlines()[-1])
     res[k] = (d["mfma"]["largest_gemm"]["launch_us"], d["ms_per_step"])
