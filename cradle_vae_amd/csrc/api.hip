@@ -19,7 +19,7 @@ extern "C" {
 
 const char* cradle_last_error(void) { return g_last_error; }
 
-int cradle_abi_version(void) { return 4; }
+int cradle_abi_version(void) { return 5; }
 
 // Layout of the descriptor structs as THIS library was compiled: out[0] = sizeof, out[1..] = offsetof of every
 // field in declaration order.  Returns the number of entries (or -1: unknown struct / buffer too small).
@@ -47,7 +47,7 @@ int cradle_struct_layout(const char* name, int64_t* out, int max_entries) {
     OFF(S, ldc); OFF(S, beta); OFF(S, act); OFF(S, bias); OFF(S, rowbias); OFF(S, ld_rowbias); OFF(S, rowbias_mode);
     OFF(S, rowbias_n); OFF(S, rowscale); OFF(S, rowscale_n); OFF(S, act_out); OFF(S, ld_act_out); OFF(S, residual);
     OFF(S, ld_residual); OFF(S, dact_src); OFF(S, ld_dact_src); OFF(S, C2); OFF(S, ldc2); OFF(S, extra_col);
-    OFF(S, precision);
+    OFF(S, precision); OFF(S, k_valid);
     return n;
   }
   if (!strcmp(name, "cradle_step_desc")) {

@@ -450,11 +450,12 @@ int cell_prep(const float* qc, const float* D_obs, const float* qc_obs, const in
 template <bool VEC>
 __global__ __launch_bounds__(256) void log_standardize_kernel(const float* __restrict__ X, const float* __restrict__ cfX,
                                                               const float* __restrict__ mean, const float* __restrict__ scale,
-                                                              float* __restrict__ xn, float* __restrict__ hascf, int N, int G) {
+                                                              float* __restrict__ xn, float* __restrict__ hascf, int N, int G,
+                                                              int ldo, float* __restrict__ xpad) {
   __shared__ float red[4];
   const int r = blockIdx.x;
   const float* src = r < N ? X + (int64_t)r * G : cfX + (int64_t)(r - N) * G;
-  float* dst = xn + (int64_t)r * G;
+  float* dst = xn + (int64_t)r * ldo;
   float s = 0.f;
   if (VEC) {
     const int G4 = G / 4;
@@ -476,10 +477,14 @@ __global__ __launch_bounds__(256) void log_standardize_kernel(const float* __res
                                nan_to_num_ref((logf(x1.z + 1.0f) - mu1.z) / sc1.z), nan_to_num_ref((logf(x1.w + 1.0f) - mu1.w) / sc1.w));
     }
   } else {
-    for (int g = threadIdx.x; g < G; g += 256) {
-      const float x = src[g];
+    // rows of ldo >= G floats, zeros behind the G values; xpad (optional): X itself in the same padded layout
+    float* xp = (xpad && r < N) ? xpad + (int64_t)r * ldo : nullptr;
+    for (int g = threadIdx.x; g < ldo; g += 256) {
+      const bool in = g < G;
+      const float x = in ? src[g] : 0.f;
       s += x;
-      dst[g] = nan_to_num_ref((logf(x + 1.0f) - mean[g]) / scale[g]);
+      dst[g] = in ? nan_to_num_ref((logf(x + 1.0f) - mean[g]) / scale[g]) : 0.f;
+      if (xp) xp[g] = x;
     }
   }
   if (r >= N) {  // counts are non-negative: the row sum is zero iff every entry is, whatever the order of the sum
@@ -489,15 +494,17 @@ __global__ __launch_bounds__(256) void log_standardize_kernel(const float* __res
 }
 
 int log_standardize(const float* X, const float* cfX, const float* log_mean, const float* log_scale, float* xn,
-                    float* hascf, int N, int G, hipStream_t stream) {
-  const bool vec = G % 4 == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)cfX % 16 == 0) && ((uintptr_t)log_mean % 16 == 0) &&
-                   ((uintptr_t)log_scale % 16 == 0) && ((uintptr_t)xn % 16 == 0);
+                    float* hascf, int N, int G, hipStream_t stream, int ldo, float* xpad) {
+  if (ldo <= 0) ldo = G;
+  CRADLE_CHECK_ARG(ldo >= G, "log_standardize: output leading dimension %d below n_phenos %d", ldo, G);
+  const bool vec = G % 4 == 0 && ldo == G && !xpad && ((uintptr_t)X % 16 == 0) && ((uintptr_t)cfX % 16 == 0) &&
+                   ((uintptr_t)log_mean % 16 == 0) && ((uintptr_t)log_scale % 16 == 0) && ((uintptr_t)xn % 16 == 0);
   if (vec)
     hipLaunchKernelGGL(log_standardize_kernel<true>, dim3(2 * N), dim3(256), 0, stream, X, cfX, log_mean, log_scale, xn, hascf,
-                       N, G);
+                       N, G, ldo, xpad);
   else
     hipLaunchKernelGGL(log_standardize_kernel<false>, dim3(2 * N), dim3(256), 0, stream, X, cfX, log_mean, log_scale, xn,
-                       hascf, N, G);
+                       hascf, N, G, ldo, xpad);
   CRADLE_CHECK_LAUNCH("log_standardize_kernel");
   return CRADLE_OK;
 }

@@ -394,17 +394,23 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
   splitk = (k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
   p.splitk = splitk;
   p.partial = workspace;
-  // branch-free loader: everything 16-byte aligned and the contiguous extents multiples of 4
-  const int64_t a_rows = layout == 2 ? p.K : p.M, a_cols = layout == 2 ? p.M : p.K;
-  const int64_t b_rows = layout == 0 ? p.N : p.K, b_cols = layout == 0 ? p.K : p.N;
+  // Branch-free loader (VEC): 16-byte buffer loads need dword alignment only on gfx950 (measured: an odd leading
+  // dimension or pointer offset costs nothing), so what it asks for is that no 16-byte load straddles the end of
+  // valid data: along K the extent must be a multiple of 4 (callers may pad K and say how much of it exists with
+  // k_valid: the range check returns zeros past it); along M / N of an MN-major operand either the extent is a
+  // multiple of 4 or the leading dimension leaves the row readable up to the next multiple (the extra rows /
+  // columns this computes are never stored).
+  const int Kv = p.k_valid > 0 ? min(p.k_valid, p.K) : p.K;
+  const int64_t a_rows = layout == 2 ? Kv : p.M, a_cols = layout == 2 ? p.M : Kv;
+  const int64_t b_rows = layout == 0 ? p.N : Kv, b_cols = layout == 0 ? Kv : p.N;
   const int64_t a_bytes = ((a_rows - 1) * p.lda + a_cols) * 4, b_bytes = ((b_rows - 1) * p.ldb + b_cols) * 4;
   p.a_bytes = (uint32_t)a_bytes;
   p.b_bytes = (uint32_t)b_bytes;
-  bool aligned = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.B % 16 == 0) && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
-                 p.K >= 4 && a_bytes < (1ll << 31) && b_bytes < (1ll << 31);
+  auto row_ok = [](int extent, int64_t ld) { return extent >= 4 && (extent % 4 == 0 || ld >= ((extent + 3) & ~3)); };
+  bool aligned = p.K >= 4 && a_bytes < (1ll << 31) && b_bytes < (1ll << 31);
   if (layout == 0) aligned = aligned && p.K % 4 == 0;
-  else if (layout == 1) aligned = aligned && p.K % 4 == 0 && p.N % 4 == 0 && p.N >= 4;
-  else aligned = aligned && p.M % 4 == 0 && p.N % 4 == 0 && p.M >= 4 && p.N >= 4;
+  else if (layout == 1) aligned = aligned && p.K % 4 == 0 && row_ok(p.N, p.ldb);
+  else aligned = aligned && row_ok(p.M, p.lda) && row_ok(p.N, p.ldb);
   if (p.precision == 1 && aligned && flops >= 1.0e9) {
     // split-bf16 kernels: 128 x 128 tiles, 64 in a dimension that pads less that way (400 -> 448 instead of 512);
     // two to four workgroups per CU, so aim at ~1024 of them (tools/bench_bf16x3.py), never below 8 K-steps per split
@@ -473,6 +479,8 @@ int cradle_gemm_f32(const cradle_gemm_desc* d, float* workspace, int64_t workspa
   p.C2 = d->C2; p.ldc2 = d->ldc2; p.extra_col = d->extra_col;
   CRADLE_CHECK_ARG(d->precision == 0 || d->precision == 1, "gemm: precision must be 0 (fp32) or 1 (bf16x3), got %d", d->precision);
   p.precision = d->precision;
+  CRADLE_CHECK_ARG(d->k_valid >= 0 && d->k_valid <= d->K, "gemm: k_valid=%d outside [0, K=%d]", d->k_valid, d->K);
+  p.k_valid = d->k_valid;
   CRADLE_CHECK_ARG(!p.C2 || p.dact_src, "gemm: C2 needs dact_src");
   CRADLE_CHECK_ARG(!p.rowbias || ((p.rb_mode == 1 || p.rb_mode == 2) && p.rb_n > 0), "gemm: bad rowbias mode");
   CRADLE_CHECK_ARG(!p.rowscale || (p.rowbias && p.rs_n > 0), "gemm: rowscale needs rowbias");

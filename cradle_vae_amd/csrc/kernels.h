@@ -34,6 +34,8 @@ struct GemmParams {
   int64_t slab;           // floats between the partial results of consecutive K splits (multiple of 4)
   int k_tiles_per_split;
   int splitk_hint;        // > 0: use this K split instead of the heuristic's (caller knows what runs beside it)
+  int k_valid;            // > 0: rows/columns of the K axis that exist in memory (K itself may be padded up to a multiple
+                          // of 4 by the caller: the operand extents then end at k_valid and the range check reads zeros)
   int precision;          // 0: fp32 MFMA (default); 1: split-bf16 (3 products) for products large enough to gain
 };
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
@@ -60,7 +62,8 @@ int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, floa
                                     void* ev_end, hipStream_t stream);
 }
 namespace cradle {
-int nb_dlogc_reduce(const float* workspace, int rows, int G, float* dlog_c, int accumulate, hipStream_t stream);
+int nb_dlogc_reduce(const float* workspace, int rows, int G, float* dlog_c, int accumulate, hipStream_t stream, int valid = -1);
+int nb_gene_consts_padded(const float* log_c, float* gene_consts, int G, int Gp, hipStream_t stream);
 
 // ---- elementwise.hip : plan / per-cell preparation
 struct DosagePlan {
@@ -103,7 +106,7 @@ int draw_noise(float* u_mask, float* eps_E, float* eps_qc_E, float* eps_z, int64
                uint64_t seed_plated, uint64_t seed_local, uint64_t step, int which, hipStream_t stream);
 
 int log_standardize(const float* X, const float* cfX, const float* log_mean, const float* log_scale, float* xn,
-                    float* hascf, int N, int G, hipStream_t stream);
+                    float* hascf, int N, int G, hipStream_t stream, int ldo = 0, float* xpad = nullptr);
 
 // ---- elementwise.hip : sampling + log-ratio terms
 // (rows of mask / E / heads are (particle, slot) pairs: row = pp*Tc + j; noise and per-treatment tables

@@ -175,9 +175,18 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
 // Per-gene constants from log_concentration: c = exp(log_c), lgamma(c), digamma(c).
 // (mlp.py:160 `concentration = torch.exp(self.log_concentration)`.)  G threads, evaluated in
 // double so the fp32 constants are correctly rounded.
-__global__ void nb_gene_consts_kernel(const float* __restrict__ log_c, float* __restrict__ gc, int G) {
+// Gp >= G: stride of the three rows; the padding genes [G, Gp) get c = 1e-30, lgamma = digamma = 0: with a count of 0
+// and a logit of -inf (mu = 0) such a gene adds -c*log1p(1e-6) ~ -1e-36 to a row's log-likelihood and exactly 0 to
+// d logits -- the rows kernel runs over Gp genes unchanged when n_phenos is not a multiple of 4.
+__global__ void nb_gene_consts_kernel(const float* __restrict__ log_c, float* __restrict__ gc, int G, int Gp) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= G) return;
+  if (g >= Gp) return;
+  if (g >= G) {
+    gc[g] = 1e-30f;
+    gc[Gp + g] = 0.f;
+    gc[2 * (int64_t)Gp + g] = 0.f;
+    return;
+  }
   const float cf = expf(log_c[g]);
   double c = (double)cf;
   // digamma by recurrence to y >= 10 then the asymptotic series
@@ -189,8 +198,8 @@ __global__ void nb_gene_consts_kernel(const float* __restrict__ log_c, float* __
   const double iy = 1.0 / y, iy2 = iy * iy;
   ps += log(y) - 0.5 * iy - iy2 * (1.0 / 12 - iy2 * (1.0 / 120 - iy2 * (1.0 / 252 - iy2 * (1.0 / 240))));
   gc[g] = cf;
-  gc[G + g] = (float)lgamma(c);
-  gc[2 * (int64_t)G + g] = (float)ps;
+  gc[Gp + g] = (float)lgamma(c);
+  gc[2 * (int64_t)Gp + g] = (float)ps;
 }
 
 // Deterministic column sum of the (rows, G) partials written by nb_rows_kernel (G % 4 == 0, rows 16-byte
@@ -200,7 +209,7 @@ __global__ void nb_gene_consts_kernel(const float* __restrict__ log_c, float* __
 // pass's GEMMs and has to fit into whatever wave slots they leave free (the 1024-thread form this replaces
 // measured 12 us alone and 170 us inside the step, waiting for whole CUs).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int rows, int G,
-                                                      float* __restrict__ out, int accumulate) {
+                                                      float* __restrict__ out, int accumulate, int valid) {
   __shared__ float4 sm[16][16];
   const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int col4 = blockIdx.x * 16 + c;  // float4 column
@@ -227,9 +236,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
     float4 t = sm[0][c];
 #pragma unroll
     for (int k = 1; k < 16; ++k) { t.x += sm[k][c].x; t.y += sm[k][c].y; t.z += sm[k][c].z; t.w += sm[k][c].w; }
-    float4* dst = reinterpret_cast<float4*>(out) + col4;
-    if (accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
-    *dst = t;
+    // columns >= valid are the padding genes of a width that is not a multiple of 4: nothing is read or written there
+    const int c0 = col4 * 4;
+    if (c0 + 3 < valid) {
+      float4* dst = reinterpret_cast<float4*>(out) + col4;
+      if (accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+      *dst = t;
+    } else {
+      const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + e < valid) out[c0 + e] = accumulate ? out[c0 + e] + tv[e] : tv[e];
+    }
   }
 }
 
@@ -295,11 +313,20 @@ using namespace cradle;
 namespace cradle {
 // d loss / d log_concentration: column sums of the `rows` = N * particle_split partial rows the rows
 // kernel left in `workspace`.  Separate from the rows launch so that the step can run it beside the backward.
-int nb_dlogc_reduce(const float* workspace, int rows, int G, float* dlog_c, int accumulate, hipStream_t stream) {
+// G: row length of the partials (a multiple of 4); valid <= G: genes that exist -- dlog_c holds `valid` floats.
+int nb_dlogc_reduce(const float* workspace, int rows, int G, float* dlog_c, int accumulate, hipStream_t stream, int valid) {
   CRADLE_CHECK_ARG(G % 4 == 0 && (uintptr_t)workspace % 16 == 0 && (uintptr_t)dlog_c % 16 == 0,
                    "nb_dlogc_reduce: G must be a multiple of 4, partials and dlog_concentration 16-byte aligned");
-  hipLaunchKernelGGL(colsum_kernel, dim3((G / 4 + 15) / 16), dim3(256), 0, stream, workspace, rows, G, dlog_c, accumulate);
+  hipLaunchKernelGGL(colsum_kernel, dim3((G / 4 + 15) / 16), dim3(256), 0, stream, workspace, rows, G, dlog_c, accumulate,
+                     valid < 0 ? G : valid);
   CRADLE_CHECK_LAUNCH("colsum_kernel");
+  return CRADLE_OK;
+}
+
+int nb_gene_consts_padded(const float* log_c, float* gene_consts, int G, int Gp, hipStream_t stream) {
+  CRADLE_CHECK_ARG(log_c && gene_consts && G > 0 && Gp >= G, "nb_gene_consts: bad arguments");
+  hipLaunchKernelGGL(nb_gene_consts_kernel, dim3((Gp + 255) / 256), dim3(256), 0, stream, log_c, gene_consts, G, Gp);
+  CRADLE_CHECK_LAUNCH("nb_gene_consts_kernel");
   return CRADLE_OK;
 }
 }  // namespace cradle
@@ -307,10 +334,7 @@ int nb_dlogc_reduce(const float* workspace, int rows, int G, float* dlog_c, int 
 extern "C" {
 
 int cradle_nb_gene_consts(const float* log_c, float* gene_consts, int G, hipStream_t stream) {
-  CRADLE_CHECK_ARG(log_c && gene_consts && G > 0, "nb_gene_consts: bad arguments");
-  hipLaunchKernelGGL(nb_gene_consts_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, log_c, gene_consts, G);
-  CRADLE_CHECK_LAUNCH("nb_gene_consts_kernel");
-  return CRADLE_OK;
+  return cradle::nb_gene_consts_padded(log_c, gene_consts, G, G, stream);
 }
 
 // tuning hook (tools/bench_nb.py): threads per workgroup (256/512/1024) and particle split; -1 = auto
@@ -359,7 +383,7 @@ int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, floa
   if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, stream);
   if (rc) return rc;
   if (!dlog_c) return CRADLE_OK;  // internal callers: the reduction follows on another stream (nb_dlogc_reduce)
-  return cradle::nb_dlogc_reduce(workspace, N * PS, G, dlog_c, accumulate_dlog_c, stream);
+  return cradle::nb_dlogc_reduce(workspace, N * PS, G, dlog_c, accumulate_dlog_c, stream, -1);
 }
 
 int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,

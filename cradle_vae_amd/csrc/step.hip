@@ -69,7 +69,7 @@ struct Work {
   float *mask, *soft, *Smask, *W0tT;
   float *yE[CRADLE_MAX_LAYERS], *rE[CRADLE_MAX_LAYERS], *headsE, *sdE, *E, *SE;
   float *yq[CRADLE_MAX_LAYERS], *rq[CRADLE_MAX_LAYERS], *headsq, *sdq, *qcE, *Sq, *qsum, *ones_q;
-  float *xn, *xW, *offB, *zoff, *offW, *vq;
+  float *xn, *Xp, *xW, *offB, *zoff, *offW, *vq;
   float *yz[CRADLE_MAX_LAYERS], *rz[CRADLE_MAX_LAYERS], *headsz, *sdz, *ltz, *klrow;
   float *wq, *yd[CRADLE_MAX_LAYERS], *rd[CRADLE_MAX_LAYERS], *logits, *recon, *nbws;
   // backward
@@ -91,10 +91,16 @@ int compact_slots(const cradle_step_desc& d) {
   return bound < d.T ? (int)bound : d.T;
 }
 
+// Row length of everything K1 touches (logits, counts, gene constants, d log_c partials): n_phenos rounded up to the
+// 16-byte vectors that kernel moves.  The padding genes carry a count of 0, a logit of -inf and c = 1e-30: they add
+// nothing to the likelihood and exact zeros to every gradient (nb_gene_consts_kernel).
+int padded_genes(int G) { return (G + 3) & ~3; }
+
 int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   Arena a(base);
   const int P = d.P, N = d.N, T = d.T, L = d.L, Q = d.Q, G = d.G, He = d.He, Hm = d.Hm, Hd = d.Hd;
   const int PP = 2 * P;
+  const int Gp = padded_genes(G);
   const int Tc = compact_slots(d);
   const int64_t PN = (int64_t)P * N, PT = (int64_t)PP * Tc;
   w.plan.kmax = d.kmax;
@@ -119,7 +125,7 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   w.cp.cwc = a.take<float>(Tc);
   w.cp.coefTc = a.take<float>(Tc);
   w.hascf = a.take<float>(N);
-  w.gene_consts = a.take<float>(3ll * G);
+  w.gene_consts = a.take<float>(3ll * Gp);
   w.mask = a.take<float>(PT * L);
   w.soft = a.take<float>(PT * L);
   w.Smask = a.take<float>(PT);
@@ -142,7 +148,8 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   w.Sq = a.take<float>((int64_t)PP * Q);
   w.qsum = a.take<float>((int64_t)P * L);
   w.ones_q = a.take<float>((int64_t)Q * L);
-  w.xn = a.take<float>(2ll * N * G);
+  w.xn = a.take<float>(2ll * N * Gp);
+  w.Xp = Gp != G ? a.take<float>((int64_t)N * Gp) : nullptr;
   w.xW = a.take<float>(2ll * N * He);
   w.offB = a.take<float>(2 * PN * L);  // offsets of the main pass, then of the counterfactual pass
   w.zoff = a.take<float>(PN * 2 * L);
@@ -161,9 +168,9 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
     w.yd[k] = a.take<float>(PN * Hd);
     w.rd[k] = k ? a.take<float>(PN * Hd) : nullptr;
   }
-  w.logits = a.take<float>(PN * G);
+  w.logits = a.take<float>(PN * Gp);
   w.recon = a.take<float>(PN);
-  w.nbws_floats = cradle_nb_workspace_floats(P, N, G);
+  w.nbws_floats = cradle_nb_workspace_floats(P, N, Gp);
   w.nbws = a.take<float>(w.nbws_floats);
   for (int i = 0; i < 2; ++i) {
     w.Gd[i] = a.take<float>(PN * Hd);
@@ -331,8 +338,9 @@ void trunk_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, float* const* y, 
 }
 
 // Output layer forward: out = y_last W_head^T + b_head.
-void head_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, int Nout, const float* ylast, float* out, int q = 0) {
-  GemmParams p = gp(ylast, H, m.W_head, H, out, Nout, M, Nout, H);
+void head_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, int Nout, const float* ylast, float* out, int q = 0,
+              int ld_out = 0) {
+  GemmParams p = gp(ylast, H, m.W_head, H, out, ld_out > 0 ? ld_out : Nout, M, Nout, H);
   p.bias = m.b_head;
   c.gemm(GEMM_NT, p, q);
 }
@@ -349,12 +357,14 @@ void head_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, int Nout, const fl
 const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, int M, int H, int Nout,
                             const float* dout, float* const* y, float* const* r, float* const* Gb, float* const* da,
                             int q, int wq, int wq2, hipEvent_t ev_dout = nullptr, hipEvent_t* ev_done = nullptr,
-                            void* ev_head_done = nullptr, int layers_per_fork = 0) {
+                            void* ev_head_done = nullptr, int layers_per_fork = 0, int ld_dout = 0) {
+  // ld_dout > Nout: rows of dout padded to a multiple of 4 with zeros (the decoder's d logits)
+  if (ld_dout <= 0) ld_dout = Nout;
   const int n = m.n_layers;
   const bool forked = wq != q;
   if (ev_done) *ev_done = nullptr;
   {  // dW_head = dout^T y_last, db_head = colsum(dout)
-    GemmParams p = gp(dout, Nout, y[n - 1], H, g.W_head, H, Nout, H, M);
+    GemmParams p = gp(dout, ld_dout, y[n - 1], H, g.W_head, H, Nout, H, M);
     p.extra_col = g.b_head;
     if (forked) {
       if (!ev_dout) ev_dout = c.record(q);
@@ -384,7 +394,8 @@ const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_p
   };
   int cur = 0;
   {  // G_{n-1} = dout W_head ; da_{n-1} = G_{n-1} * slope(r_{n-1})
-    GemmParams p = gp(dout, Nout, m.W_head, H, Gb[cur], H, M, H, Nout);
+    GemmParams p = gp(dout, ld_dout, m.W_head, H, Gb[cur], H, M, H, ld_dout);
+    p.k_valid = Nout;  // W_head has Nout rows: the loader's range check supplies zeros for the padding
     p.dact_src = n > 1 ? r[n - 1] : y[0]; p.ld_ds = H; p.C2 = da[n - 1]; p.ldc2 = H;
     c.gemm(GEMM_NN, p, q);
   }
@@ -412,10 +423,23 @@ __global__ void fill_kernel(float* p, int64_t n, float v) {
   if (i < n) p[i] = v;
 }
 
+__global__ void fill_pad_columns_kernel(float* p, int rows, int G, int Gp, float v) {
+  const int pad = Gp - G;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (int64_t)rows * pad) p[(i / pad) * Gp + G + i % pad] = v;
+}
+
+int fill_pad_columns(float* p, int rows, int G, int Gp, float v, hipStream_t s) {
+  const int64_t n = (int64_t)rows * (Gp - G);
+  hipLaunchKernelGGL(fill_pad_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, rows, G, Gp, v);
+  CRADLE_CHECK_LAUNCH("fill_pad_columns_kernel");
+  return CRADLE_OK;
+}
+
 int check_desc(const cradle_step_desc& d) {
   CRADLE_CHECK_ARG(d.P > 0 && d.N > 0 && d.T > 0 && d.L > 0 && d.Q > 0 && d.G > 0 && d.He > 0 && d.Hm > 0 && d.Hd > 0,
                    "elbo_step: all sizes must be positive");
-  CRADLE_CHECK_ARG(d.G % 4 == 0, "elbo_step: n_phenos=%d must be a multiple of 4", d.G);
+  CRADLE_CHECK_ARG(d.G >= 4, "elbo_step: n_phenos=%d below 4", d.G);
   CRADLE_CHECK_ARG(d.kmax >= 1 && d.kmax <= 64, "elbo_step: kmax=%d out of range [1,64]", d.kmax);
   const cradle_mlp_ptrs* ms[4] = {&d.emb, &d.qce, &d.enc, &d.dec};
   const cradle_mlp_ptrs* gs[4] = {&d.d_emb, &d.d_qce, &d.d_enc, &d.d_dec};
@@ -459,7 +483,7 @@ int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* d) {
 // Where an intermediate of the last step lives inside desc->workspace (for parity tests: the mask and
 // the latent draws are compared with the reference's own).  name: "mask" (2P*Tc*L, rows (particle,
 // slot)), "E" (same), "qc_E" (2P*Q*L), "z_offset" (P*N rows of [z_basal | D@(E*mask)], ld 2L),
-// "logits" (P*N*G; overwritten by d logits when gradients were computed).  Returns the element
+// "logits" (P*N rows of n_phenos rounded up to a multiple of 4; overwritten by d logits when gradients were computed).  Returns the element
 // count and the pointer, or -1 for an unknown name.
 int64_t cradle_elbo_step_intermediate(const cradle_step_desc* d, const char* name, const float** ptr) {
   if (!d || !name || !ptr || !d->workspace) return -1;
@@ -470,7 +494,7 @@ int64_t cradle_elbo_step_intermediate(const cradle_step_desc* d, const char* nam
   if (!strcmp(name, "E")) { *ptr = w.E; return PP * Tc * d->L; }
   if (!strcmp(name, "qc_E")) { *ptr = w.qcE; return PP * d->Q * d->L; }
   if (!strcmp(name, "z_offset")) { *ptr = w.zoff; return PN * 2 * d->L; }
-  if (!strcmp(name, "logits")) { *ptr = w.logits; return PN * d->G; }
+  if (!strcmp(name, "logits")) { *ptr = w.logits; return PN * padded_genes(d->G); }
   // the step's own draws (when the caller passed no noise)
   if (!strcmp(name, "u_mask")) { *ptr = w.u_mask; return PP * d->T * d->L; }
   if (!strcmp(name, "eps_E")) { *ptr = w.eps_E; return PP * d->T * d->L; }
@@ -490,6 +514,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   const int P = d.P, N = d.N, T = d.T, L = d.L, Q = d.Q, G = d.G, He = d.He, Hm = d.Hm, Hd = d.Hd;
   const int Tc = w.plan.Tc;
   const int PP = 2 * P, PN = P * N, PT = PP * Tc;
+  const int Gp = padded_genes(G);  // == G for the widths K1 takes as they are
   int rc = 0;
   hipStream_t s = c.st[0], s1 = c.st[1], s2 = c.st[2];
   const float* Wenc0 = d.enc.W[0];
@@ -524,9 +549,12 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   }
   STEP(build_dosage_plan(d.D, N, T, w.plan, s1));
   hipEvent_t ev_plan = c.record(1);
-  STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s1));
+  STEP(log_standardize(d.X, d.cfX, d.log_mean, d.log_scale, w.xn, w.hascf, N, G, s1, Gp, w.Xp));
   {
-    GemmParams p = gp(w.xn, G, Wenc0, ldenc, w.xW, He, 2 * N, He, G);  // x Wx^T, X and cfX
+    // x Wx^T, X and cfX.  Padded width: xn holds zeros behind a row's G values, so whatever the loader reads behind
+    // Wx's G columns (the offset block of the same row; nothing past the matrix) meets a zero
+    GemmParams p = gp(w.xn, Gp, Wenc0, ldenc, w.xW, He, 2 * N, He, Gp);
+    p.k_valid = G;
     p.splitk_hint = 4;  // beside the embedding encoder's chain: 8 us less to the join than the stand-alone heuristic's 2
     c.gemm(GEMM_NT, p, 1);
   }
@@ -560,7 +588,10 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   c.gemm(GEMM_NT, gp(w.qcE, L, Wenc0 + G + L, ldenc, w.vq, He, PP * Q, He, L), 2);  // qc_E Wqc^T
   hipEvent_t ev_vq = c.record(2);
   c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L), 2);        // bad-variant shift per particle
-  STEP(cradle_nb_gene_consts(d.log_concentration, w.gene_consts, G, s2));
+  STEP(nb_gene_consts_padded(d.log_concentration, w.gene_consts, G, Gp, s2));
+  if (Gp != G) {  // logits of the padding genes: -inf (K1 leaves zeros there -- their gradient -- so every step)
+    STEP(fill_pad_columns(w.logits, PN, G, Gp, -INFINITY, s2));
+  }
   hipEvent_t ev_s2 = c.record(2);
 
   if (w.plan.tmap) c.wait(0, ev_plan);
@@ -615,19 +646,20 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   trunk_fwd(c, d.dec, PN, Hd, w.yd, w.rd);
   if (g_stop_after == 5) return c.rc;
   PROBE(6);
-  head_fwd(c, d.dec, PN, Hd, G, w.yd[d.dec.n_layers - 1], w.logits);
+  head_fwd(c, d.dec, PN, Hd, G, w.yd[d.dec.n_layers - 1], w.logits, 0, Gp);
   if (d.ev_gemm_end && probe_at() < 10) (void)hipEventRecord((hipEvent_t)d.ev_gemm_end, s);
   if (c.rc) return c.rc;
   if (g_stop_after == 6) return c.rc;
   }
   {
+  const float* Xk = w.Xp ? w.Xp : d.X;  // counts in K1's row length (written beside the standardised rows on stream 1)
   if (!d.compute_grads) {
     if (d.ev_k1_begin) (void)hipEventRecord((hipEvent_t)d.ev_k1_begin, s);
-    STEP(cradle_nb_logprob_fwd(w.logits, G, d.X, G, d.library_size, w.gene_consts, w.recon, P, N, G, s));
+    STEP(cradle_nb_logprob_fwd(w.logits, Gp, Xk, Gp, d.library_size, w.gene_consts, w.recon, P, N, Gp, s));
     if (d.ev_k1_end) (void)hipEventRecord((hipEvent_t)d.ev_k1_end, s);
   } else {  // events bracket the rows kernel only (the launch the roofline in bench.py describes)
-    STEP(cradle_nb_logprob_fwd_bwd_timed(w.logits, G, w.logits, G, d.X, G, d.library_size, w.gene_consts, w.cp.grow,
-                                         w.recon, nullptr, 0, w.nbws, w.nbws_floats, P, N, G, d.ev_k1_begin,
+    STEP(cradle_nb_logprob_fwd_bwd_timed(w.logits, Gp, w.logits, Gp, Xk, Gp, d.library_size, w.gene_consts, w.cp.grow,
+                                         w.recon, nullptr, 0, w.nbws, w.nbws_floats, P, N, Gp, d.ev_k1_begin,
                                          d.ev_k1_end, s));
   }
   }
@@ -636,7 +668,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   hipEvent_t ev_k1 = c.record(0);
   c.wait(2, ev_k1);
   STEP(gaussE_fwd(w.headsE, nz_E, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.SE, PP, T, Tc, w.plan.tmap, L, s2));
-  if (d.compute_grads) STEP(nb_dlogc_reduce(w.nbws, N * cradle_nb_particle_split(P, N), G, d.d_log_concentration, 0, s2));
+  if (d.compute_grads) STEP(nb_dlogc_reduce(w.nbws, N * cradle_nb_particle_split(P, N), Gp, d.d_log_concentration, 0, s2, G));
   STEP(finalize_loss(w.recon, w.cp.wrec, w.ltz, w.klrow, w.Smask, w.SE, w.Sq, w.cp.cwc, w.cp.cwq, d.beta, P, N, Tc, Q,
                      d.flags, d.out, s2));
   if (!d.compute_grads) {
@@ -651,7 +683,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   PROBE(10);
   hipEvent_t ev_dec = nullptr;
   const float* da0d = head_trunk_bwd(c, d.dec, d.d_dec, PN, Hd, G, w.logits, w.yd, w.rd, w.Gd, w.dad, 0, 1, 2, ev_k1,
-                                     &ev_dec, d.ev_bucket[0]);
+                                     &ev_dec, d.ev_bucket[0], 0, Gp);
   if (c.rc) return c.rc;
   PROBE(11);
   if (!ev_dec) ev_dec = c.record(0);
@@ -684,7 +716,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   }
   STEP(enc_combine_bwd(dpre, d.qc, w.doffW, w.dxW, w.dvq, P, N, Q, He, s, s2, 2));  // dvq: feeds dWqc and q(qc_E) only
   {  // dWx = dxW^T logstd([X; cfX]); db0 = colsum(dxW)
-    GemmParams p = gp(w.dxW, He, w.xn, G, dWenc0, ldenc, He, G, 2 * N);
+    GemmParams p = gp(w.dxW, He, w.xn, Gp, dWenc0, ldenc, He, G, 2 * N);
     p.extra_col = d.d_enc.b[0];
     c.gemm(GEMM_TN, p, 1);
   }

@@ -93,7 +93,7 @@ PROTOTYPES = {
 }
 
 MAX_LAYERS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MlpPtrs(ctypes.Structure):
@@ -149,6 +149,7 @@ class GemmDesc(ctypes.Structure):
         ("C2", ctypes.c_void_p), ("ldc2", i64),
         ("extra_col", ctypes.c_void_p),
         ("precision", i32),
+        ("k_valid", i32),
     ]
 
 

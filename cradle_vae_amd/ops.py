@@ -211,17 +211,23 @@ def gemm(
     residual: Optional[torch.Tensor] = None, dact_src: Optional[torch.Tensor] = None,
     out2: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None, rowbias_mode: int = 0,
     rowbias_n: int = 0, rowscale: Optional[torch.Tensor] = None, extra_col: Optional[torch.Tensor] = None,
-    workspace: Optional[torch.Tensor] = None, repeat: int = 1, precision: str = "f32",
+    workspace: Optional[torch.Tensor] = None, repeat: int = 1, precision: str = "f32", k_valid: int = 0,
 ) -> torch.Tensor:
     """fp32 MFMA GEMM with the fused epilogue of ``cradle_gemm_f32`` (see the header).
     ``repeat`` > 1 relaunches the same GEMM from C (benchmarking aid).  ``precision``: "f32" (exact fp32 MFMA) or
-    "bf16x3" (split-bf16, three products per element pair, for products of >= 1 GFLOP)."""
+    "bf16x3" (split-bf16, three products per element pair, for products of >= 1 GFLOP).  ``k_valid`` > 0: the
+    inner dimension has k_valid real entries and is padded by the caller to the next multiple of 4 (see
+    ``cradle_gemm_desc.k_valid``): an operand may then show either extent along its inner axis."""
     if layout == NT:
         (M, K), (N, K2) = A.shape, B.shape
     elif layout == NN:
         (M, K), (K2, N) = A.shape, B.shape
     else:
         (K, M), (K2, N) = A.shape, B.shape
+    if k_valid > 0:
+        if {K, K2} - {k_valid, (k_valid + 3) & ~3}:
+            raise hip.CradleHipError(f"gemm: inner dimensions {K}, {K2} are neither k_valid={k_valid} nor its padding")
+        K = K2 = (k_valid + 3) & ~3
     if K != K2:
         raise hip.CradleHipError(f"gemm: inner dimensions differ ({K} vs {K2})")
     if out is None:
@@ -235,6 +241,7 @@ def gemm(
     d.C, d.ldc = _mat(out)
     d.beta, d.act = beta, int(act)
     d.precision = PRECISIONS[precision]
+    d.k_valid = k_valid
     d.bias = hip.ptr(bias)
     if rowbias is not None:
         d.rowbias, d.ld_rowbias = _mat(rowbias)

@@ -33,7 +33,7 @@ def supports(lm) -> bool:
         return False
     if m.sum_mode or not isinstance(m.decoder, LibraryGammaPoissonSharedConcentrationResidualMLP):
         return False
-    if m.n_phenos % 4 != 0:
+    if m.n_phenos < 4:
         return False
     if not next(lm.parameters()).is_cuda:
         raise hip.CradleHipError("cradle_vae_amd runs on the GPU only: move the module to a cuda device (no CPU path)")

@@ -137,6 +137,12 @@ typedef struct cradle_gemm_desc {
                       v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~1e-6..1e-5 relative per dot product), used for
                       products of >= 1 GFLOP with 16-byte aligned operands, fp32 otherwise.  Optional mode, no
                       counterpart in the reference (which computes in fp32). */
+  int k_valid;     /* 0: the operands hold K rows/columns along the inner dimension.  > 0 (and < K): they hold only
+                      k_valid; K is that count rounded up by the caller so that the 16-byte loader applies (K % 4 == 0),
+                      and the loader's range check supplies zeros from the end of an operand's last k_valid-long row on.
+                      For a K-major operand (A of NT/NN, B of NT) rows other than the last must be readable up to K and
+                      hold finite values there (its leading dimension >= K); an MN-major operand (B of NN, both of TN)
+                      simply ends after k_valid rows. */
 } cradle_gemm_desc;
 
 /* workspace (optional, may be NULL): lets small-output / long-K problems split along K. */

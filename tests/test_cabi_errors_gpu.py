@@ -50,9 +50,9 @@ def test_step_rejects_bad_descriptors():
     assert lib.cradle_elbo_step(None, hip.stream()) != 0
     assert b"null descriptor" in lib.cradle_last_error()
     d = hip.StepDesc()
-    d.P, d.N, d.T, d.L, d.Q, d.G, d.He, d.Hm, d.Hd, d.kmax = 1, 4, 3, 2, 1, 10, 4, 4, 4, 2  # G % 4 != 0
+    d.P, d.N, d.T, d.L, d.Q, d.G, d.He, d.Hm, d.Hd, d.kmax = 1, 4, 3, 2, 1, 3, 4, 4, 4, 2  # fewer than 4 genes
     assert lib.cradle_elbo_step(ctypes.byref(d), hip.stream()) != 0
-    assert b"multiple of 4" in lib.cradle_last_error()
+    assert b"below 4" in lib.cradle_last_error()
     d.G, d.kmax = 12, 0
     assert lib.cradle_elbo_step(ctypes.byref(d), hip.stream()) != 0
     assert b"kmax" in lib.cradle_last_error()

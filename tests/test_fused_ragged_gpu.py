@@ -1,84 +1,56 @@
-"""Fused HIP ELBO step against the CPU oracle (fp64) on ragged shapes the golden fixtures do not
-hold: odd latent / hidden widths (the non-vectorised GEMM loaders, partial tiles everywhere), a
-single cell, all-control batches, treatments without any cell, the compact treatment axis with
-unused slots, three encoder layers.  Same bar as the golden tests: loss and every loss term within
-1e-4 relative, every gradient within 2e-3 of its largest entry."""
+"""Gene counts that are not a multiple of 4 (real datasets: whatever the highly-variable-gene filter left) through the
+fused HIP step, against the fp64 oracle at the bars of tests/test_fused_fullsize_gpu.py.  The step pads the row
+length of everything K1 touches to the next multiple of 4 (padding genes: count 0, logit -inf, concentration 1e-30 --
+they add nothing to the likelihood and exact zeros to every gradient) and lets the GEMM loader's range check supply
+zeros where an operand ends inside a 16-byte load; the reference has no such limit (any n_phenos), so neither may the
+drop-in.  One width per residue mod 4, the last at the Norman widths (split-bf16 mode included)."""
 import dataclasses
 
 import pytest
 import torch
 
-from tests.test_fused_step_gpu import run_fused
-from tests.test_modular_gpu import DEV, GRAD_L2_RTOL, build_loss_module
+from tests.test_fused_fullsize_gpu import compare_with_oracle
+from tests.test_modular_gpu import DEV
 
 pytestmark = pytest.mark.gpu
 
-# name: (N, P, G, T, L, Hd, He, Hm, layers(dec, enc, emb), kmax, tweak)
-CASES = {
-    "odd_everything": (37, 2, 36, 11, 7, 13, 10, 9, (1, 1, 2), 8, None),
-    "single_cell": (1, 3, 8, 5, 3, 6, 6, 6, (1, 1, 1), 8, None),
-    "all_control": (9, 2, 12, 4, 5, 8, 8, 8, (2, 1, 2), 8, "control"),
-    "compact_sparse": (5, 2, 16, 40, 3, 8, 8, 8, (1, 2, 3), 2, None),
-    "compact_all_control": (6, 2, 16, 30, 4, 8, 8, 8, (1, 1, 2), 2, "control"),
-    "no_counterfactuals_but_one": (12, 2, 20, 6, 6, 8, 12, 8, (1, 1, 2), 8, "one_cf"),
-}
 
-
-def make_case(name):
+@pytest.mark.parametrize("base,n_cells,n_phenos,n_latent,seed", [
+    ("mid", 64, 301, 16, 5),        # G % 4 == 1, small-tile GEMM kernels
+    ("mid", 96, 1202, 15, 6),       # G % 4 == 2, odd latent width: encoder rows start at odd offsets
+    ("norman", 256, 5003, 200, 7),  # G % 4 == 3, the bench shape's widths: large-tile kernels, split-K, bf16x3
+])
+def test_fused_step_with_ragged_gene_count_matches_oracle(base, n_cells, n_phenos, n_latent, seed):
     from cradle_vae_amd import synthetic as syn
-    from oracle import cradle_oracle as co
 
-    N, P, G, T, L, Hd, He, Hm, (ld, le, lm_), kmax, tweak = CASES[name]
-    shape = dataclasses.replace(
-        syn.TINY, n_cells=N, n_particles=P, n_phenos=G, n_treatments=T, n_latent=L, decoder_n_hidden=Hd,
-        basal_encoder_n_hidden=He, embedding_encoder_n_hidden=Hm)
-    b = syn.make_batch(shape, seed=11)
-    if tweak == "control":
-        b["D"].zero_()
-    if tweak == "one_cf":
-        b["cfX"][1:] = 0.0
-        b["cfX"][0] = b["X"][0] + 1.0
-    cfg = dict(
-        n_latent=L, n_treatments=T, n_phenos=G, n_qc=1, decoder_n_layers=ld, decoder_n_hidden=Hd,
-        basal_encoder_n_layers=le, basal_encoder_n_hidden=He, embedding_encoder_n_layers=lm_,
-        embedding_encoder_n_hidden=Hm, mask_prior_prob=shape.mask_prior_prob, embedding_prior_scale=1.0,
-        beta=0.7, alpha=0.6 if name in ("single_cell", "all_control", "compact_sparse") else None, n_particles=P)
-    # (alpha=None is the reference's qc-fraction weighting, loss_modules.py:137-139, which zeroes the
-    # reconstruction term of a batch without a QC-failed cell: those cases get a fixed alpha)
-    params = co.init_params(**{k: cfg[k] for k in cfg if k not in ("beta", "alpha", "n_particles")},
-                            log_x_mean=b["log_x_mean"], log_x_std=b["log_x_std"], seed=4)
-    noise, cf_noise = syn.make_noise(shape, 1), syn.make_noise(shape, 2)
-    return cfg, params, b, noise, cf_noise, kmax
+    shape = dataclasses.replace(syn.SHAPES[base], name=f"{base}_g{n_phenos}", n_cells=n_cells, n_phenos=n_phenos,
+                                n_latent=n_latent)
+    precisions = (("f32", 2e-5), ("bf16x3", 1e-2)) if base == "norman" else (("f32", 2e-5),)
+    worst = compare_with_oracle(shape, 2, seed, compact=False, precisions=precisions)
+    print(f"\n{shape.name}: worst relative L2 gradient error / loss error per precision: {worst}")
+    if base == "norman":
+        assert worst["bf16x3"] > worst["f32"]
 
 
-@pytest.mark.parametrize("name", list(CASES))
-def test_fused_step_matches_oracle_on_ragged_shapes(name):
-    from oracle import cradle_oracle as co
+def test_padding_genes_leave_no_trace():
+    """d logits of the padding columns are exact zeros after a training step, and the gradient of log_concentration
+    has exactly n_phenos entries (the float behind it in the arena is untouched)."""
+    from cradle_vae_amd import synthetic as syn
+    from cradle_vae_amd.trainer import TrainStep
+    import bench
 
-    cfg, params, b, noise, cf_noise, kmax = make_case(name)
-    f64 = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
-    ref_loss, ref_metrics, _, ref_grads = co.elbo_loss_and_grads(
-        f64(params), X=b["X"].double(), D=b["D"].double(), qc=b["qc"].double(), cfX=b["cfX"].double(),
-        library_size=b["library_size"].double(), D_obs_counts=b["D_obs_counts"].double(),
-        qc_obs_counts=b["qc_obs_counts"].double(), noise=f64(noise), cf_noise=f64(cf_noise),
-        n_particles=cfg["n_particles"], beta=cfg["beta"], alpha=cfg["alpha"])
-    assert torch.isfinite(ref_loss)
-
-    dev = lambda d: {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in d.items()}
-    case = dict(cfg=cfg, params=dev(params), batch=dev(b), noise=dev(noise), cf_noise=dev(cf_noise))
-    lm = build_loss_module(case)
-    lm.max_dosages_per_cell = kmax
-    loss, metrics, grads = run_fused(lm, case)
-    d = lm._fused.desc
-    assert (d.N * d.kmax < d.T) == name.startswith("compact")
-
-    rtol = 1e-4
-    assert abs(float(loss.detach()) - float(ref_loss)) <= rtol * max(1.0, abs(float(ref_loss))), (float(loss), float(ref_loss))
-    for k, v in ref_metrics.items():
-        assert abs(float(metrics[k]) - float(v)) <= rtol * max(1.0, abs(float(v))), (k, float(metrics[k]), float(v))
-    for k, g in ref_grads.items():
-        got = grads[k].detach().cpu().double()
-        err = float((got - g).abs().max()) / max(float(g.abs().max()), 1e-8)
-        assert err <= 2e-3, (k, err)
-        l2 = float((got - g).norm()) / max(float(g.norm()), 1e-12)
-        assert l2 <= GRAD_L2_RTOL, (k, l2)
+    shape = dataclasses.replace(syn.SHAPES["mid"], name="mid_g301", n_phenos=301)
+    lm, batch = bench.build(shape, DEV, seed=3)
+    st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0)
+    f = st.fused
+    off = f.arena.offsets["log_c"]
+    f.arena.grad[off + 301: off + 304] = 7.0  # the arena pads segments to 64 floats: these belong to nobody
+    out = f.run(compute_grads=True, X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"],
+                qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
+                n_particles=shape.n_particles)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out[:7]).all())
+    d = f.intermediate("logits").view(shape.n_particles * shape.n_cells, 304)
+    assert torch.equal(d[:, 301:], torch.zeros_like(d[:, 301:]))
+    assert float(d[:, :301].abs().max()) > 0
+    assert torch.equal(f.arena.grad[off + 301: off + 304], torch.full((3,), 7.0, device=DEV))

@@ -184,3 +184,54 @@ def test_bf16x3_small_or_unaligned_products_stay_fp32():
     assert torch.equal(ops.gemm(ops.NT, x, W, precision="bf16x3"), ops.gemm(ops.NT, x, W))
     with pytest.raises(KeyError):
         ops.gemm(ops.NT, x, W, precision="fp8")
+
+
+def _view(rows, cols, ld, offset, seed, tail=float("nan")):
+    """(rows, cols) view with leading dimension ld starting `offset` floats into a NaN-filled buffer: whatever a
+    kernel reads outside the view and lets reach a stored result shows."""
+    buf = torch.full((offset + rows * ld + 8,), tail, device=DEV)
+    v = buf[offset:offset + rows * ld].view(rows, ld)[:, :cols]
+    v.copy_(_rand(rows, cols, seed=seed))
+    return v
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_ragged_operands_odd_offsets_and_leading_dimensions(precision):
+    """Operands whose rows start at odd float offsets and whose M / N extents are not multiples of 4 (a weight block
+    inside a wider matrix, n_phenos = 4k+1..3) -- the 16-byte loader takes them (dword alignment is all
+    buffer_load_dwordx4 needs on gfx950); the slack it may read behind a row never reaches a stored element."""
+    from cradle_vae_amd import hip, ops
+
+    close = _close if precision == "f32" else _close_b3
+    M, N, K = 1283, 403, 1000  # 1 GFLOP: the split-bf16 kernels take it when asked
+    x, W = _view(M, K, K + 3, 1, 1), _view(N, K, K + 5, 3, 2)
+    close(ops.gemm(ops.NT, x, W, precision=precision), x.double() @ W.double().T, K)
+    Wn = _view(K, N, N + 2, 1, 3)  # NN: B is MN-major, 403 columns in rows of 405
+    close(ops.gemm(ops.NN, x, Wn, precision=precision), x.double() @ Wn.double(), K)
+    dy, xin = _view(K, M, M + 1, 2, 4), _view(K, N, N + 1, 1, 5)  # TN: both MN-major
+    db = torch.empty(M, device=DEV)
+    ws = torch.empty(hip.load().cradle_gemm_workspace_floats(ops.TN, M, N, K, 1), device=DEV)
+    dW = ops.gemm(ops.TN, dy, xin, extra_col=db, workspace=ws, precision=precision)
+    close(dW, dy.double().T @ xin.double(), K)
+    close(db, dy.double().sum(0), K)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("G", [1201, 1202, 1203])
+def test_padded_inner_dimension_with_k_valid(G, precision):
+    """The decoder's output layer at a gene count that is not a multiple of 4: d logits rows are padded with zeros to
+    Gp, the weight has G rows and NaNs behind them -- the range check, not the memory, supplies the padding."""
+    from cradle_vae_amd import ops
+
+    close = _close if precision == "f32" else _close_b3
+    Gp, M, H = (G + 3) & ~3, 1100, 400
+    dl = torch.zeros(M, Gp, device=DEV)
+    dl[:, :G] = _rand(M, G, seed=1)
+    Wh = _view(G, H, H, 0, 2)  # contiguous (G, H), NaN behind the last row
+    ref = dl[:, :G].double() @ Wh.double()
+    close(ops.gemm(ops.NN, dl, Wh, k_valid=G, precision=precision), ref, G)
+    # x Wx^T: the weight's rows continue with other (finite) columns, which meet the zeros of the padded input
+    Wx = _view(H, G + 40, G + 40, 0, 3)[:, :G]
+    close(ops.gemm(ops.NT, dl, Wx, k_valid=G, precision=precision), dl[:, :G].double() @ Wx.double().T, G)
+    with pytest.raises(ops.hip.CradleHipError):
+        ops.gemm(ops.NN, dl, Wh[: G - 1], k_valid=G)
