@@ -76,7 +76,8 @@ def estimate_model_average_treatment_effect(
     plan = F_hip.DosagePlan(D_all, kmax) if kmax <= 64 else None
     share_z = dosage_independent_variables is not None and "z_basal" in dosage_independent_variables
     gene_consts = ops.nb_gene_consts(model.decoder.log_concentration.detach())
-    sums = torch.zeros((C, G), device=device, dtype=torch.float32)
+    sums_rows = torch.zeros((C, (G + 3) & ~3), device=device, dtype=torch.float32)  # the sampler's row length
+    sums = sums_rows[:, :G]
 
     world, rank = parallel.world_and_rank()
     starts = list(range(0, n_particles, batch_size))
@@ -119,6 +120,6 @@ def estimate_model_average_treatment_effect(
             call_seed = (seed * 7919 + ci) * 4099 + s0
             ops.nb_sample_accumulate(
                 p_x_good.logits, lib, gene_consts, c, n, sums=sums[s0:s1], method=method, sampler=sampler, seed=call_seed)
-    parallel.allreduce_sum_(sums, world)
+    parallel.allreduce_sum_(sums_rows, world)
     means = sums / n_particles  # :199-200
     return (means[1:] - means[:1]).cpu().numpy()

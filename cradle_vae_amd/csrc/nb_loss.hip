@@ -18,7 +18,9 @@
 
 namespace cradle {
 
-template <int VPT, int NT, bool BWD>
+// TAIL: the gene count is not a multiple of 4 (Gv < G): the last 16-byte vector of a row is masked.  A separate
+// instantiation: the masks cost the aligned case 6 us of its 38 when they are compiled in (register pressure).
+template <int VPT, int NT, bool BWD, bool TAIL>
 __global__ __launch_bounds__(NT) void nb_rows_kernel(
     const float* logits, int64_t ld_logits,       // (P*N, ld) rows r = p*N + n
     float* dlogits, int64_t ld_dlogits,           // BWD: gradient rows, may alias logits
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
     const float* __restrict__ grow,               // BWD: (P*N) d loss / d out[r]
     float* __restrict__ out,                      // (P*N) sum_g log p
     float* __restrict__ dlogc_part,               // BWD: (N*PS, G) partial d loss / d log_c
-    int P, int N, int G, int PS) {
+    int P, int N, int G, int PS, int Gv) {  // G: row length run (multiple of 4); Gv <= G: genes that exist
   __shared__ float2 red[6][NT / 64];
   const int n = blockIdx.x;
   const int ps = blockIdx.y;
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
   for (int j = 0; j < VPT; ++j) {
     const int k = j * NT + tid;
     if (k < G4) {
-      x[j] = X4[k];
+      x[j] = TAIL ? mask_gene_tail(X4[k], k, Gv, 0.f) : X4[k];
       c[j] = C4[k];
       const float4 lgc = LGC4[k];
       float4 dpsi = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
       const int k = j * NT + tid;
-      dst[j] = (k < G4) ? L4[k] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      dst[j] = (k < G4) ? (TAIL ? mask_gene_tail(L4[k], k, Gv, -INFINITY) : L4[k])
+                        : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     }
   };
   if (ps < P) load_row(ps, nxt);
@@ -257,13 +260,19 @@ static int g_nb_tune_nt = -1, g_nb_tune_ps = -1;
 template <bool BWD>
 static int launch_nb_rows(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
                           const float* X, int64_t ldx, const float* lib, const float* gene_consts,
-                          const float* grow, float* out, float* dlogc_part, int P, int N, int G, int PS,
+                          const float* grow, float* out, float* dlogc_part, int P, int N, int G, int PS, int Gv,
                           hipStream_t stream) {
   const int G4 = G / 4;
   dim3 grid(N, PS);
-#define CRADLE_NB_LAUNCH(VPT, NT)                                                                       \
-  hipLaunchKernelGGL((nb_rows_kernel<VPT, NT, BWD>), grid, dim3(NT), 0, stream, logits, ld_logits,      \
-                     dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, dlogc_part, P, N, G, PS)
+#define CRADLE_NB_LAUNCH(VPT, NT)                                                                            \
+  do {                                                                                                       \
+    if (Gv < G)                                                                                              \
+      hipLaunchKernelGGL((nb_rows_kernel<VPT, NT, BWD, true>), grid, dim3(NT), 0, stream, logits, ld_logits, \
+                         dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, dlogc_part, P, N, G, PS, Gv); \
+    else                                                                                                     \
+      hipLaunchKernelGGL((nb_rows_kernel<VPT, NT, BWD, false>), grid, dim3(NT), 0, stream, logits, ld_logits, \
+                         dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, dlogc_part, P, N, G, PS, Gv); \
+  } while (0)
   // thread count / values per thread: as many waves per CU as the register budget allows (all
   // workgroups of a 512-cell batch are then resident at once); override via cradle_nb_tune
   int nt = g_nb_tune_nt;
@@ -297,10 +306,10 @@ static int check_common(const void* logits, const void* X, const void* lib, cons
                         int P, int N, int G, int64_t ld_logits, int64_t ldx) {
   CRADLE_CHECK_ARG(logits && X && lib && gc && out, "nb_logprob: null pointer argument");
   CRADLE_CHECK_ARG(P > 0 && N > 0 && G > 0, "nb_logprob: P=%d N=%d G=%d must be positive", P, N, G);
-  CRADLE_CHECK_ARG(G % 4 == 0, "nb_logprob: n_genes=%d must be a multiple of 4 (pad the gene axis)", G);
-  CRADLE_CHECK_ARG(ld_logits >= G && ld_logits % 4 == 0 && ldx >= G && ldx % 4 == 0,
-                   "nb_logprob: leading dimensions (%lld, %lld) must be >= G and multiples of 4",
-                   (long long)ld_logits, (long long)ldx);
+  const int Gp = (G + 3) & ~3;  // rows are run as Gp genes; the tail behind G is masked in the kernel
+  CRADLE_CHECK_ARG(ld_logits >= Gp && ld_logits % 4 == 0 && ldx >= Gp && ldx % 4 == 0,
+                   "nb_logprob: leading dimensions (%lld, %lld) must be multiples of 4 and >= n_genes rounded up to 4 (%d)",
+                   (long long)ld_logits, (long long)ldx, Gp);
   CRADLE_CHECK_ARG(((uintptr_t)logits % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)gc % 16 == 0),
                    "nb_logprob: logits, X and gene_consts must be 16-byte aligned");
   return CRADLE_OK;
@@ -334,7 +343,7 @@ int nb_gene_consts_padded(const float* log_c, float* gene_consts, int G, int Gp,
 extern "C" {
 
 int cradle_nb_gene_consts(const float* log_c, float* gene_consts, int G, hipStream_t stream) {
-  return cradle::nb_gene_consts_padded(log_c, gene_consts, G, G, stream);
+  return cradle::nb_gene_consts_padded(log_c, gene_consts, G, (G + 3) & ~3, stream);
 }
 
 // tuning hook (tools/bench_nb.py): threads per workgroup (256/512/1024) and particle split; -1 = auto
@@ -358,7 +367,7 @@ int cradle_nb_logprob_fwd(const float* logits, int64_t ld_logits, const float* X
   if (rc) return rc;
   const int PS = cradle_nb_particle_split(P, N);
   return launch_nb_rows<false>(logits, ld_logits, nullptr, 0, X, ldx, lib, gene_consts, nullptr, out, nullptr, P,
-                               N, G, PS, stream);
+                               N, (G + 3) & ~3, PS, G, stream);
 }
 
 // Optional events (cradle_event_create handles) are recorded on `stream` immediately around the
@@ -371,19 +380,20 @@ int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, floa
   int rc = check_common(logits, X, lib, gene_consts, out, P, N, G, ld_logits, ldx);
   if (rc) return rc;
   CRADLE_CHECK_ARG(dlogits && grow && workspace, "nb_logprob_fwd_bwd: null pointer argument");
-  CRADLE_CHECK_ARG(ld_dlogits >= G && ld_dlogits % 4 == 0 && (uintptr_t)dlogits % 16 == 0,
-                   "nb_logprob_fwd_bwd: dlogits must be 16-byte aligned with ld >= G, ld %% 4 == 0");
+  const int Gp = (G + 3) & ~3;
+  CRADLE_CHECK_ARG(ld_dlogits >= Gp && ld_dlogits % 4 == 0 && (uintptr_t)dlogits % 16 == 0,
+                   "nb_logprob_fwd_bwd: dlogits must be 16-byte aligned with ld %% 4 == 0, ld >= n_genes rounded up to 4");
   const int PS = cradle_nb_particle_split(P, N);
-  CRADLE_CHECK_ARG(workspace_floats >= (int64_t)N * PS * G && (uintptr_t)workspace % 16 == 0,
+  CRADLE_CHECK_ARG(workspace_floats >= (int64_t)N * PS * Gp && (uintptr_t)workspace % 16 == 0,
                    "nb_logprob_fwd_bwd: workspace needs %lld floats, 16-byte aligned (got %lld)",
-                   (long long)((int64_t)N * PS * G), (long long)workspace_floats);
+                   (long long)((int64_t)N * PS * Gp), (long long)workspace_floats);
   if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, stream);
   rc = launch_nb_rows<true>(logits, ld_logits, dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, workspace,
-                            P, N, G, PS, stream);
+                            P, N, Gp, PS, G, stream);
   if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, stream);
   if (rc) return rc;
   if (!dlog_c) return CRADLE_OK;  // internal callers: the reduction follows on another stream (nb_dlogc_reduce)
-  return cradle::nb_dlogc_reduce(workspace, N * PS, G, dlog_c, accumulate_dlog_c, stream, -1);
+  return cradle::nb_dlogc_reduce(workspace, N * PS, Gp, dlog_c, accumulate_dlog_c, stream, G);
 }
 
 int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
@@ -398,7 +408,7 @@ int cradle_nb_logprob_fwd_bwd(const float* logits, int64_t ld_logits, float* dlo
 }
 
 int64_t cradle_nb_workspace_floats(int P, int N, int G) {
-  return (int64_t)N * cradle_nb_particle_split(P, N) * G;
+  return (int64_t)N * cradle_nb_particle_split(P, N) * ((G + 3) & ~3);
 }
 
 }  // extern "C"

@@ -15,6 +15,20 @@ namespace cradle {
 constexpr float kMuEps = 1e-4f;    // mlp.py:161
 constexpr float kRateMin = 1e-6f;  // mlp.py:163
 
+// A float4 of genes 4k .. 4k+3 of a row whose last valid gene is n_valid - 1: the components behind it take `fill`.
+// Gene counts that are not a multiple of 4 are run as rows of the next multiple (the 16-byte vectors these kernels
+// move); whatever the memory holds there never enters the arithmetic.
+__device__ __forceinline__ float4 mask_gene_tail(float4 v, int k, int n_valid, float fill) {
+  const int g = 4 * k;
+  if (g + 3 >= n_valid) {
+    if (g >= n_valid) v.x = fill;
+    if (g + 1 >= n_valid) v.y = fill;
+    if (g + 2 >= n_valid) v.z = fill;
+    v.w = fill;
+  }
+  return v;
+}
+
 __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 // natural log / exp on the bare v_log_f32 / v_exp_f32 (1 ulp, no denormal fix-up code): every
 // argument here is a normal float (rates >= 1e-6, 1 + rate >= 1, counts >= 1), and an

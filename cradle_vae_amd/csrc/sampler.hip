@@ -131,13 +131,15 @@ enum { SAMPLER_NB = 0, SAMPLER_MEAN = 1 };
 enum { METHOD_MEAN = 0, METHOD_PERTURBSEQ = 1 };
 
 // logits rows r = p * C + t (particle-major, the (P, n, G) layout model.forward flattens).
-template <int VPT>
+// TAIL: Gv < G (a gene count that is not a multiple of 4): the last 16-byte vector of a row is masked
+template <int VPT, bool TAIL>
 __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* __restrict__ logits, int64_t ld,
                                                                    const float* __restrict__ lib, int lib_n,
                                                                    const float* __restrict__ gene_consts, float* __restrict__ sums,
                                                                    float* __restrict__ samples, int P, int C, int G, int method,
                                                                    int sampler, uint32_t seed_lo, uint32_t seed_hi,
-                                                                   uint32_t row_offset, float* __restrict__ partials) {
+                                                                   uint32_t row_offset, float* __restrict__ partials, int Gv) {
+  // G: row length run (a multiple of 4; sums, samples and gene_consts have rows of G floats); Gv <= G: genes that exist
   __shared__ float2 red[6][4];
   const int t = blockIdx.x, tid = threadIdx.x;
   const int G4 = G >> 2;
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
       const int k = j * 256 + tid;
-      v[j] = k < G4 ? L4[k] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      v[j] = k < G4 ? (TAIL ? mask_gene_tail(L4[k], k, Gv, -INFINITY) : L4[k])
+                    : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
       mx = fmaxf(fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)), mx);
     }
     mx = block_max<256>(mx, reinterpret_cast<float*>(red[rbase]));
@@ -188,7 +191,9 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
         for (int q = 0; q < 4; ++q) {
           const float rate = fmaxf(cc[q] / (e[q] * mu_scale + kMuEps), kRateMin);
           float x;
-          if (sampler == SAMPLER_MEAN) {
+          if (TAIL && k * 4 + q >= Gv) {
+            x = 0.f;  // behind the last gene
+          } else if (sampler == SAMPLER_MEAN) {
             x = cc[q] / rate;
           } else if (nb_inversion_ok(cc[q], rate)) {
             x = sample_nb_inversion(cc[q], rate, u01(ur[q]));
@@ -270,7 +275,7 @@ static int particle_splits(int P, int C) {
 int64_t cradle_nb_sample_workspace_floats(int P, int C, int G) {
   if (P <= 0 || C <= 0 || G <= 0) return 0;
   const int s = particle_splits(P, C);
-  return s > 1 ? (int64_t)s * C * G : 0;
+  return s > 1 ? (int64_t)s * C * ((G + 3) & ~3) : 0;
 }
 
 // sums (C, G) += sum over the P particles of transform(x[p, t, :]), x ~ GammaPoisson(c, rate(logits)).
@@ -283,7 +288,10 @@ int cradle_nb_sample_accumulate_ws(const float* logits, int64_t ld_logits, const
                                    int sampler, uint64_t seed, uint32_t row_offset, float* workspace,
                                    int64_t workspace_floats, hipStream_t stream) {
   CRADLE_CHECK_ARG(logits && library && gene_consts && sums && P > 0 && C > 0 && G > 0, "nb_sample: bad arguments");
-  CRADLE_CHECK_ARG(G % 4 == 0 && ld_logits % 4 == 0 && ld_logits >= G, "nb_sample: G and ld must be multiples of 4");
+  const int Gv = G;
+  G = (G + 3) & ~3;  // rows are run as the next multiple of 4 genes: sums / samples / gene_consts rows have that length
+  CRADLE_CHECK_ARG(ld_logits % 4 == 0 && ld_logits >= G,
+                   "nb_sample: ld must be a multiple of 4 and >= n_genes rounded up to a multiple of 4");
   CRADLE_CHECK_ARG((uintptr_t)logits % 16 == 0 && (uintptr_t)sums % 16 == 0 && (uintptr_t)gene_consts % 16 == 0 &&
                        (uintptr_t)samples % 16 == 0 && (uintptr_t)workspace % 16 == 0,
                    "nb_sample: pointers must be 16-byte aligned");
@@ -296,8 +304,16 @@ int cradle_nb_sample_accumulate_ws(const float* logits, int64_t ld_logits, const
   while (splits > 1 && (int64_t)splits * C * G > workspace_floats) --splits;
   float* partials = splits > 1 ? workspace : nullptr;
 #define CRADLE_SAMPLE_LAUNCH(VPT)                                                                                      \
-  hipLaunchKernelGGL((nb_sample_accumulate_kernel<VPT>), dim3(C, splits), dim3(256), 0, stream, logits, ld_logits, library, \
-                     library_n, gene_consts, sums, samples, P, C, G, method, sampler, lo, hi, row_offset, partials)
+  do {                                                                                                                 \
+    if (Gv < G)                                                                                                        \
+      hipLaunchKernelGGL((nb_sample_accumulate_kernel<VPT, true>), dim3(C, splits), dim3(256), 0, stream, logits,      \
+                         ld_logits, library, library_n, gene_consts, sums, samples, P, C, G, method, sampler, lo, hi,  \
+                         row_offset, partials, Gv);                                                                    \
+    else                                                                                                               \
+      hipLaunchKernelGGL((nb_sample_accumulate_kernel<VPT, false>), dim3(C, splits), dim3(256), 0, stream, logits,     \
+                         ld_logits, library, library_n, gene_consts, sums, samples, P, C, G, method, sampler, lo, hi,  \
+                         row_offset, partials, Gv);                                                                    \
+  } while (0)
   if (G4 <= 256) CRADLE_SAMPLE_LAUNCH(1);
   else if (G4 <= 512) CRADLE_SAMPLE_LAUNCH(2);
   else if (G4 <= 1024) CRADLE_SAMPLE_LAUNCH(4);

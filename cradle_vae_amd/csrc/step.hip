@@ -92,8 +92,8 @@ int compact_slots(const cradle_step_desc& d) {
 }
 
 // Row length of everything K1 touches (logits, counts, gene constants, d log_c partials): n_phenos rounded up to the
-// 16-byte vectors that kernel moves.  The padding genes carry a count of 0, a logit of -inf and c = 1e-30: they add
-// nothing to the likelihood and exact zeros to every gradient (nb_gene_consts_kernel).
+// 16-byte vectors that kernel moves.  K1 reads the genes behind n_phenos as count 0, logit -inf (mask_gene_tail) and
+// c = 1e-30 (nb_gene_consts_kernel): they add nothing to the likelihood and exact zeros to every gradient.
 int padded_genes(int G) { return (G + 3) & ~3; }
 
 int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
@@ -423,19 +423,6 @@ __global__ void fill_kernel(float* p, int64_t n, float v) {
   if (i < n) p[i] = v;
 }
 
-__global__ void fill_pad_columns_kernel(float* p, int rows, int G, int Gp, float v) {
-  const int pad = Gp - G;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < (int64_t)rows * pad) p[(i / pad) * Gp + G + i % pad] = v;
-}
-
-int fill_pad_columns(float* p, int rows, int G, int Gp, float v, hipStream_t s) {
-  const int64_t n = (int64_t)rows * (Gp - G);
-  hipLaunchKernelGGL(fill_pad_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, rows, G, Gp, v);
-  CRADLE_CHECK_LAUNCH("fill_pad_columns_kernel");
-  return CRADLE_OK;
-}
-
 int check_desc(const cradle_step_desc& d) {
   CRADLE_CHECK_ARG(d.P > 0 && d.N > 0 && d.T > 0 && d.L > 0 && d.Q > 0 && d.G > 0 && d.He > 0 && d.Hm > 0 && d.Hd > 0,
                    "elbo_step: all sizes must be positive");
@@ -589,9 +576,6 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   hipEvent_t ev_vq = c.record(2);
   c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L), 2);        // bad-variant shift per particle
   STEP(nb_gene_consts_padded(d.log_concentration, w.gene_consts, G, Gp, s2));
-  if (Gp != G) {  // logits of the padding genes: -inf (K1 leaves zeros there -- their gradient -- so every step)
-    STEP(fill_pad_columns(w.logits, PN, G, Gp, -INFINITY, s2));
-  }
   hipEvent_t ev_s2 = c.record(2);
 
   if (w.plan.tmap) c.wait(0, ev_plan);
@@ -655,11 +639,11 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   const float* Xk = w.Xp ? w.Xp : d.X;  // counts in K1's row length (written beside the standardised rows on stream 1)
   if (!d.compute_grads) {
     if (d.ev_k1_begin) (void)hipEventRecord((hipEvent_t)d.ev_k1_begin, s);
-    STEP(cradle_nb_logprob_fwd(w.logits, Gp, Xk, Gp, d.library_size, w.gene_consts, w.recon, P, N, Gp, s));
+    STEP(cradle_nb_logprob_fwd(w.logits, Gp, Xk, Gp, d.library_size, w.gene_consts, w.recon, P, N, G, s));
     if (d.ev_k1_end) (void)hipEventRecord((hipEvent_t)d.ev_k1_end, s);
   } else {  // events bracket the rows kernel only (the launch the roofline in bench.py describes)
     STEP(cradle_nb_logprob_fwd_bwd_timed(w.logits, Gp, w.logits, Gp, Xk, Gp, d.library_size, w.gene_consts, w.cp.grow,
-                                         w.recon, nullptr, 0, w.nbws, w.nbws_floats, P, N, Gp, d.ev_k1_begin,
+                                         w.recon, nullptr, 0, w.nbws, w.nbws_floats, P, N, G, d.ev_k1_begin,
                                          d.ev_k1_end, s));
   }
   }

@@ -26,7 +26,10 @@ class _Linear(torch.autograd.Function):
         M, N = x2.shape[0], W.shape[0]
         res2 = residual.reshape(M, N) if residual is not None else None
         act_out = torch.empty((M, N), device=x.device, dtype=torch.float32) if (act and residual is not None) else None
-        y = ops.gemm(ops.NT, x2, W, bias=b, act=act, act_out=act_out, residual=res2)
+        # an output width that is not a multiple of 4 (the decoder's logits over an arbitrary gene count) gets rows of
+        # the next multiple: the NB kernels (K1, K9) then take the result as it is
+        out = ops.empty_gene_rows(M, N, x.device) if (N % 4 and not act and residual is None) else None
+        y = ops.gemm(ops.NT, x2, W, out, bias=b, act=act, act_out=act_out, residual=res2)
         ctx.act = act
         ctx.has_res = residual is not None
         ctx.has_bias = b is not None
@@ -37,7 +40,9 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, W, r = ctx.saved_tensors
-        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.stride(1) != 1 or ctx.act:
+            dy2 = dy2.contiguous()
         da = dy2 * torch.where(r > 0, 1.0, LEAKY_SLOPE) if ctx.act else dy2
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
@@ -75,7 +80,9 @@ class _NBLogProb(torch.autograd.Function):
 
 def nb_logprob(logits: torch.Tensor, X: torch.Tensor, lib: torch.Tensor, log_c: torch.Tensor, P: int) -> torch.Tensor:
     """logits (P*N, G) -> (P*N,) summed log-likelihood (loss_modules.py:134-135,143)."""
-    return _NBLogProb.apply(logits.contiguous(), X.contiguous(), lib.contiguous(), log_c.contiguous(), P)
+    if logits.stride(-1) != 1:
+        logits = logits.contiguous()  # (row-strided views pass: ops.nb_logprob_* read the leading dimension)
+    return _NBLogProb.apply(logits, X.contiguous(), lib.contiguous(), log_c.contiguous(), P)
 
 
 # ---------------------------------------------------------------------------------------------

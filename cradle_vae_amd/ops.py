@@ -33,10 +33,40 @@ class _timed:
             KERNEL_TIMERS.append((self.name, self.s, self.e))
 
 
+def _gp(G: int) -> int:
+    """Row length the NB kernels run a gene axis of G at: the next multiple of 4 (16-byte vectors)."""
+    return (G + 3) & ~3
+
+
+def _gene_rows(t: torch.Tensor, fresh: bool = False) -> torch.Tensor:
+    """``t`` (rows, G) as a view whose rows are 16-byte aligned and at least _gp(G) floats apart -- itself when it already
+    is one (G % 4 == 0 and contiguous, or a [:, :G] view of a padded buffer as F_hip.linear makes for such widths),
+    else a copy into a padded buffer.  The kernels never use what lies between G and the row stride."""
+    rows, G = t.shape
+    if (not fresh and t.stride(1) == 1 and t.stride(0) >= _gp(G) and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+            and t.dtype == torch.float32):
+        return t
+    buf = torch.empty((rows, _gp(G)), device=t.device, dtype=torch.float32)
+    view = buf[:, :G]
+    if not fresh:
+        view.copy_(t)
+    return view
+
+
+def _rp(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Pointer of a _gene_rows view (rows contiguous, row stride checked there)."""
+    return None if t is None else t.data_ptr()
+
+
+def empty_gene_rows(rows: int, G: int, device) -> torch.Tensor:
+    """Uninitialised (rows, G) fp32 view in the layout _gene_rows asks for."""
+    return torch.empty((rows, _gp(G)), device=device, dtype=torch.float32)[:, :G]
+
+
 def nb_gene_consts(log_concentration: torch.Tensor) -> torch.Tensor:
-    """(G,) log-concentration -> (3,G) [c, lgamma(c), digamma(c)]  (mlp.py:160)."""
+    """(G,) log-concentration -> (3, Gp) [c, lgamma(c), digamma(c)], Gp = G rounded up to 4  (mlp.py:160)."""
     G = log_concentration.numel()
-    out = torch.empty((3, G), device=log_concentration.device, dtype=torch.float32)
+    out = torch.empty((3, _gp(G)), device=log_concentration.device, dtype=torch.float32)
     hip.check(hip.load().cradle_nb_gene_consts(hip.ptr(log_concentration), hip.ptr(out), G, hip.stream()), "nb_gene_consts")
     return out
 
@@ -53,10 +83,11 @@ def nb_logprob_fwd(logits: torch.Tensor, X: torch.Tensor, lib: torch.Tensor, gen
     """sum_g log GammaPoisson(X | softmax(logits), lib, c) per (particle, cell) row -> (P*N,)."""
     N, G = X.shape
     _nb_check(logits, X, lib, P, N, G)
+    logits, X = _gene_rows(logits), _gene_rows(X)
     out = torch.empty((P * N,), device=X.device, dtype=torch.float32)
     hip.check(
         hip.load().cradle_nb_logprob_fwd(
-            hip.ptr(logits), logits.stride(0), hip.ptr(X), X.stride(0), hip.ptr(lib), hip.ptr(gene_consts),
+            _rp(logits), logits.stride(0), _rp(X), X.stride(0), hip.ptr(lib), hip.ptr(gene_consts),
             hip.ptr(out), P, N, G, hip.stream()),
         "nb_logprob_fwd",
     )
@@ -71,8 +102,9 @@ def nb_logprob_fwd_bwd(
     N, G = X.shape
     _nb_check(logits, X, lib, P, N, G)
     lib_ = hip.load()
+    logits, X = _gene_rows(logits), _gene_rows(X)  # (inplace then overwrites the padded copy, if one was made)
     out = torch.empty((P * N,), device=X.device, dtype=torch.float32)
-    dlogits = logits if inplace else torch.empty_like(logits)
+    dlogits = logits if inplace else empty_gene_rows(P * N, G, X.device)
     accumulate = dlog_c is not None
     if dlog_c is None:
         dlog_c = torch.empty((G,), device=X.device, dtype=torch.float32)
@@ -85,7 +117,7 @@ def nb_logprob_fwd_bwd(
         KERNEL_TIMERS.append(("nb_logprob_fwd_bwd", ev))
     hip.check(
         lib_.cradle_nb_logprob_fwd_bwd_timed(
-            hip.ptr(logits), logits.stride(0), hip.ptr(dlogits), dlogits.stride(0), hip.ptr(X), X.stride(0),
+            _rp(logits), logits.stride(0), _rp(dlogits), dlogits.stride(0), _rp(X), X.stride(0),
             hip.ptr(lib), hip.ptr(gene_consts), hip.ptr(grow), hip.ptr(out), hip.ptr(dlog_c), int(accumulate),
             hip.ptr(workspace), workspace.numel(), P, N, G, ev.begin if ev else None, ev.end if ev else None,
             hip.stream()),
@@ -106,24 +138,30 @@ def nb_sample_accumulate(
     and adds the (optionally perturbseq-normalised) draws of each condition, summed over its
     particles, to ``sums`` (C, G).  -> (sums, samples or None)."""
     G = logits.shape[1]
-    if logits.shape[0] != P * C or lib.numel() not in (1, C) or gene_consts.shape[-1] != G:
+    if logits.shape[0] != P * C or lib.numel() not in (1, C) or gene_consts.shape[-1] != _gp(G):
         raise hip.CradleHipError(
             f"nb_sample: shape mismatch logits {tuple(logits.shape)} lib {tuple(lib.shape)} for P={P} C={C}")
     if sums is None:
-        sums = torch.zeros((C, G), device=logits.device, dtype=torch.float32)
+        sums = torch.zeros((C, _gp(G)), device=logits.device, dtype=torch.float32)[:, :G]
     if sums.shape != (C, G):
         raise hip.CradleHipError(f"nb_sample: sums has shape {tuple(sums.shape)}, expected {(C, G)}")
-    samples = torch.empty((P * C, G), device=logits.device, dtype=torch.float32) if return_samples else None
+    # the kernel's rows of sums / samples are _gp(G) floats long: a caller's sums in another layout is added to afterwards
+    logits = _gene_rows(logits)
+    own_sums = sums.stride(1) == 1 and sums.stride(0) == _gp(G) and sums.data_ptr() % 16 == 0
+    ksums = sums if own_sums else torch.zeros((C, _gp(G)), device=logits.device, dtype=torch.float32)[:, :G]
+    samples = empty_gene_rows(P * C, G, logits.device) if return_samples else None
     lib_ = hip.load()
     need = lib_.cradle_nb_sample_workspace_floats(P, C, G)
     ws = _sample_workspace(logits.device, need) if need > 0 else None
     hip.check(
         lib_.cradle_nb_sample_accumulate_ws(
-            hip.ptr(logits), logits.stride(0), hip.ptr(lib), lib.numel(), hip.ptr(gene_consts), hip.ptr(sums),
-            hip.ptr(samples), P, C, G, METHODS[method], SAMPLERS[sampler], seed & (2**64 - 1), row_offset & 0xFFFFFFFF,
+            _rp(logits), logits.stride(0), hip.ptr(lib), lib.numel(), hip.ptr(gene_consts), _rp(ksums),
+            _rp(samples), P, C, G, METHODS[method], SAMPLERS[sampler], seed & (2**64 - 1), row_offset & 0xFFFFFFFF,
             hip.ptr(ws), need if ws is not None else 0, hip.stream()),
         "nb_sample_accumulate",
     )
+    if not own_sums:
+        sums += ksums
     return sums, samples
 
 

@@ -61,8 +61,12 @@ int cradle_stream_wait_event(cradle_stream_t stream, void* ev);
  * the caller to `out`.
  *
  * logits  (P*N, ld_logits)  decoder pre-softmax outputs, row r = p*N + n
- * X       (N, ldx)          integer-valued counts;  library (N);  G % 4 == 0, G <= 16384
- * gene_consts (3, G)        written by cradle_nb_gene_consts from log_concentration
+ * X       (N, ldx)          integer-valued counts;  library (N);  G <= 16384
+ * gene_consts (3, Gp)       written by cradle_nb_gene_consts from log_concentration
+ * Any gene count G (the reference has no restriction): the kernels move 16-byte vectors, so rows are run as
+ * Gp = G rounded up to a multiple of 4 genes -- ld_logits, ld_dlogits and ldx must be multiples of 4 and >= Gp, the
+ * rows of gene_consts and of the workspace have Gp floats -- and whatever the memory holds in columns G..Gp-1 never
+ * enters the arithmetic (read as count 0, logit -inf; d logits there is written as 0, d log_concentration has G entries).
  * out     (P*N)             sum_g log p(X[n,g] | row r)
  */
 int cradle_nb_gene_consts(const float* log_concentration, float* gene_consts, int G, cradle_stream_t stream);
@@ -299,7 +303,8 @@ int cradle_adam_step_regions(float* params, const float* grads, float* exp_avg, 
  *   mlp.py:153-166 (softmax -> mu -> rate) + pyro GammaPoisson.sample at model.py:131
  *   (rate' ~ Gamma(c, rate), x ~ Poisson(rate')) + average_treatment_effects.py:171-176,190-195
  *   (method "perturbseq": log2(1e4*x/sum_g x + 1); X_sums[t] += sum over particles).
- * sums (C, G) is accumulated into (+=).  samples: NULL or (P*C, G) raw draws
+ * sums (C, Gp) is accumulated into (+=).  samples: NULL or (P*C, Gp) raw draws; Gp = G rounded up to a multiple of 4
+ * (row length of sums, samples, gene_consts; ld_logits >= Gp; columns G..Gp-1 receive zeros)
  * (predictor.py:228-251 sample_observations).  library: 1 or C entries.  method: 0 raw counts,
  * 1 perturbseq.  sampler: 0 Gamma-Poisson draw (Philox4x32-10 keyed by seed, counter = gene,
  * row_offset + r, draw index), 1 the distribution mean c/rate (deterministic, for parity tests). */

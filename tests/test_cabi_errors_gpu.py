@@ -30,12 +30,12 @@ def test_gemm_rejects_bad_descriptors():
 
 def test_sampler_and_adam_reject_bad_arguments():
     lib = hip.load()
-    P, C, G = 2, 3, 10  # G not a multiple of 4
+    P, C, G = 2, 3, 10  # rows are run as 12 genes: a leading dimension of 10 leaves no room for that
     logits, lib_sz = torch.randn(P * C, 12, device=DEV), torch.ones(1, device=DEV)
     consts, sums = torch.ones(3, 12, device=DEV), torch.zeros(C, 12, device=DEV)
-    rc = lib.cradle_nb_sample_accumulate(hip.ptr(logits), 12, hip.ptr(lib_sz), 1, hip.ptr(consts), hip.ptr(sums), None,
+    rc = lib.cradle_nb_sample_accumulate(hip.ptr(logits), 10, hip.ptr(lib_sz), 1, hip.ptr(consts), hip.ptr(sums), None,
                                          P, C, G, 0, 0, 1, 0, hip.stream())
-    assert rc != 0 and b"multiples of 4" in lib.cradle_last_error()
+    assert rc != 0 and b"multiple of 4" in lib.cradle_last_error()
     rc = lib.cradle_nb_sample_accumulate(hip.ptr(logits), 12, hip.ptr(lib_sz), 2, hip.ptr(consts), hip.ptr(sums), None,
                                          P, C, 12, 0, 0, 1, 0, hip.stream())
     assert rc != 0 and b"library" in lib.cradle_last_error()  # 1 or C library sizes

@@ -32,17 +32,18 @@ def test_fused_step_matches_reference(name):
     check_against_golden(case, loss, metrics, grads)
 
 
-@pytest.mark.parametrize("kmax", [8, 2])
-def test_fused_equals_modular_at_replogle_like_shape(kmax):
+@pytest.mark.parametrize("kmax,n_phenos", [(8, 1200), (2, 1200), (2, 1201)])
+def test_fused_equals_modular_at_replogle_like_shape(kmax, n_phenos):
     """T > N, L = 100, two-layer-free encoder: sizes the golden fixtures do not reach.  kmax=2 (the
     data set's true bound) makes N*kmax < T, i.e. the step runs q(M), q(E|M) on the compact axis of
-    treatments present in the batch; kmax=8 keeps the full axis."""
+    treatments present in the batch; kmax=8 keeps the full axis.  n_phenos=1201: a gene count that is not a
+    multiple of 4 through both paths (the modular one hands K1 row-padded views of the logits and counts)."""
     import dataclasses
 
     from cradle_vae_amd import synthetic as syn
     from oracle import cradle_oracle as co
 
-    shape = dataclasses.replace(syn.REPLOGLE, n_cells=96, n_phenos=1200, n_treatments=700, n_particles=3)
+    shape = dataclasses.replace(syn.REPLOGLE, n_cells=96, n_phenos=n_phenos, n_treatments=700, n_particles=3)
     b = syn.make_batch(shape, seed=5, device=DEV)
     cfg = dict(
         n_latent=shape.n_latent, n_treatments=shape.n_treatments, n_phenos=shape.n_phenos, n_qc=1,

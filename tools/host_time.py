@@ -1,0 +1,28 @@
+"""How long the host takes to enqueue one training step (all of its launches, events and the optimiser) against how
+long the GPU takes to run it: python tools/host_time.py [shape] [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from cradle_vae_amd import synthetic as syn
+from cradle_vae_amd.trainer import TrainStep
+
+shape = syn.SHAPES[sys.argv[1] if len(sys.argv) > 1 else "norman"]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+lm, batch = bench.build(shape, "cuda:0", seed=1000)
+st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0)
+for _ in range(20):
+    st(batch, n_particles=shape.n_particles)
+torch.cuda.synchronize()
+host, total = [], []
+for _ in range(10):
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st(batch, n_particles=shape.n_particles)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    host.append((t1 - t0) / steps * 1e3)
+    total.append((t2 - t0) / steps * 1e3)
+host.sort(); total.sort()
+print(f"{shape.name}: host enqueue {host[len(host)//2]:.3f} ms/step (min {host[0]:.3f}), enqueue+drain {total[len(total)//2]:.3f} ms/step "
+      f"over bursts of {steps} steps")
