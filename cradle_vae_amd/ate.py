@@ -96,6 +96,7 @@ def estimate_model_average_treatment_effect(
         del gs
         # conditions in slabs so that one decoder pass stays within MAX_ROWS_PER_LAUNCH rows
         slab = max(1, min(MAX_ROWS_PER_LAUNCH, MAX_LOGIT_FLOATS // G) // c)
+        slab = -(-C // -(-C // slab))  # equal slabs: 237 conditions go as 119 + 118, not 209 + 28 (a small GEMM tail)
         z_shared = None
         for s0 in range(0, C, slab):
             s1 = min(C, s0 + slab)

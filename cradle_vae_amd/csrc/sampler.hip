@@ -132,23 +132,37 @@ enum { METHOD_MEAN = 0, METHOD_PERTURBSEQ = 1 };
 
 // logits rows r = p * C + t (particle-major, the (P, n, G) layout model.forward flattens).
 // TAIL: Gv < G (a gene count that is not a multiple of 4): the last 16-byte vector of a row is masked
-template <int VPT, bool TAIL>
-__global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* __restrict__ logits, int64_t ld,
+// NT threads own VPT 16-byte vectors of genes each.  The per-gene search loops are chains of dependent operations
+// (a reciprocal among them) of a length that differs from lane to lane: what hides their latency is waves, and a
+// thread's registers grow with VPT (v, c, acc: 12 VPT, plus the unrolled search) -- 230 VGPRs and two waves per
+// SIMD at VPT = 6.  So wide rows go to 512 / 1024 threads with VPT <= 2..4 (four waves per SIMD).
+template <int VPT, int NT, bool TAIL>
+__global__ __launch_bounds__(NT) void nb_sample_accumulate_kernel(const float* __restrict__ logits, int64_t ld,
                                                                    const float* __restrict__ lib, int lib_n,
                                                                    const float* __restrict__ gene_consts, float* __restrict__ sums,
                                                                    float* __restrict__ samples, int P, int C, int G, int method,
                                                                    int sampler, uint32_t seed_lo, uint32_t seed_hi,
                                                                    uint32_t row_offset, float* __restrict__ partials, int Gv) {
   // G: row length run (a multiple of 4; sums, samples and gene_consts have rows of G floats); Gv <= G: genes that exist
-  __shared__ float2 red[6][4];
+  __shared__ float2 red[6][NT / 64];
+  // Genes that need the Gamma -> Poisson composition (a few hundred operations, against ~20 for an inversion) are not
+  // drawn where they are met -- one such lane would hold its whole wave for every gene slot, and at 10 % of the genes
+  // every wave has one -- but queued per row in LDS (the gene's rate goes to slot[g], its index to queue[]) and
+  // then drawn by the whole workgroup, one queued gene per lane; the owners collect the counts from slot[g].
+  // Draws are keyed by (gene, row), so who draws does not matter.
+  extern __shared__ float dyn_lds[];
+  float* slot = dyn_lds;                                  // [G]
+  int* queue = reinterpret_cast<int*>(dyn_lds + G);       // [G]
+  __shared__ int queued;
   const int t = blockIdx.x, tid = threadIdx.x;
   const int G4 = G >> 2;
   const Philox ph{seed_lo, seed_hi};
+  if (tid == 0) queued = 0;  // (the first push comes after the barriers of the first row's softmax)
   const float libt = lib[lib_n == 1 ? 0 : t];
   float4 c[VPT], acc[VPT];
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
-    const int k = j * 256 + tid;
+    const int k = j * NT + tid;
     c[j] = k < G4 ? reinterpret_cast<const float4*>(gene_consts)[k] : make_float4(1.f, 1.f, 1.f, 1.f);
     acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -161,12 +175,12 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-      const int k = j * 256 + tid;
+      const int k = j * NT + tid;
       v[j] = k < G4 ? (TAIL ? mask_gene_tail(L4[k], k, Gv, -INFINITY) : L4[k])
                     : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
       mx = fmaxf(fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)), mx);
     }
-    mx = block_max<256>(mx, reinterpret_cast<float*>(red[rbase]));
+    mx = block_max<NT>(mx, reinterpret_cast<float*>(red[rbase]));
     float se = 0.f;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
@@ -174,13 +188,14 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
       v[j].z = fast_exp(v[j].z - mx); v[j].w = fast_exp(v[j].w - mx);
       se += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     }
-    se = block_sum<256>(se, reinterpret_cast<float*>(red[rbase + 1]));
+    se = block_sum<NT>(se, reinterpret_cast<float*>(red[rbase + 1]));
     const float mu_scale = libt / se;
     float xs = 0.f;
+    uint32_t deferred = 0;  // bit j*4+q: this thread's gene (j, q) is in the queue
     const uint32_t row = row_offset + (uint32_t)r;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-      const int k = j * 256 + tid;
+      const int k = j * NT + tid;
       if (k < G4) {
         float* e = reinterpret_cast<float*>(&v[j]);
         const float* cc = reinterpret_cast<const float*>(&c[j]);
@@ -198,16 +213,45 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
           } else if (nb_inversion_ok(cc[q], rate)) {
             x = sample_nb_inversion(cc[q], rate, u01(ur[q]));
           } else {
-            x = sample_gamma_poisson(cc[q], rate, ph, (uint32_t)(k * 4 + q), row);
+            slot[k * 4 + q] = rate;
+            queue[atomicAdd(&queued, 1)] = k * 4 + q;
+            deferred |= 1u << (j * 4 + q);
+            x = 0.f;
           }
           e[q] = x;
           xs += x;
         }
-        if (samples) reinterpret_cast<float4*>(samples + r * (int64_t)G)[k] = v[j];
+      }
+    }
+    if (sampler == SAMPLER_NB) {
+      __syncthreads();
+      const int n_queued = queued;
+      for (int i = tid; i < n_queued; i += NT) {
+        const int g = queue[i];
+        slot[g] = sample_gamma_poisson(gene_consts[g], slot[g], ph, (uint32_t)g, row);
+      }
+      __syncthreads();
+      if (tid == 0) queued = 0;  // the next row pushes only after the two barriers of its softmax
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        float* e = reinterpret_cast<float*>(&v[j]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (deferred & (1u << (j * 4 + q))) {
+            e[q] = slot[(j * NT + tid) * 4 + q];
+            xs += e[q];
+          }
+      }
+    }
+    if (samples) {
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        const int k = j * NT + tid;
+        if (k < G4) reinterpret_cast<float4*>(samples + r * (int64_t)G)[k] = v[j];
       }
     }
     if (method == METHOD_PERTURBSEQ) {
-      xs = block_sum<256>(xs, reinterpret_cast<float*>(red[rbase + 2]));
+      xs = block_sum<NT>(xs, reinterpret_cast<float*>(red[rbase + 2]));
       const float sc = 1e4f / xs;  // 0/0 -> NaN like the reference (:174)
 #pragma unroll
       for (int j = 0; j < VPT; ++j) {
@@ -225,7 +269,7 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
     float4* P4 = reinterpret_cast<float4*>(partials + ((int64_t)blockIdx.y * C + t) * G);
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-      const int k = j * 256 + tid;
+      const int k = j * NT + tid;
       if (k < G4) P4[k] = acc[j];
     }
     return;
@@ -233,7 +277,7 @@ __global__ __launch_bounds__(256) void nb_sample_accumulate_kernel(const float* 
   float4* S4 = reinterpret_cast<float4*>(sums + (int64_t)t * G);
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
-    const int k = j * 256 + tid;
+    const int k = j * NT + tid;
     if (k < G4) {
       float4 s = S4[k];
       s.x += acc[j].x; s.y += acc[j].y; s.z += acc[j].z; s.w += acc[j].w;
@@ -262,6 +306,10 @@ __global__ __launch_bounds__(256) void partial_sums_kernel(const float* __restri
 using namespace cradle;
 
 extern "C" {
+
+static int g_sample_tune_nt = -1;
+// tuning hook (tools/bench_sampler.py): threads per workgroup (256 / 512 / 1024); -1 = automatic
+void cradle_nb_sample_tune(int threads) { g_sample_tune_nt = threads; }
 
 static int particle_splits(int P, int C) {
   // ~2048 workgroups per launch, at least 4 particles per workgroup
@@ -303,25 +351,44 @@ int cradle_nb_sample_accumulate_ws(const float* logits, int64_t ld_logits, const
   int splits = workspace ? particle_splits(P, C) : 1;
   while (splits > 1 && (int64_t)splits * C * G > workspace_floats) --splits;
   float* partials = splits > 1 ? workspace : nullptr;
-#define CRADLE_SAMPLE_LAUNCH(VPT)                                                                                      \
+#define CRADLE_SAMPLE_LAUNCH(VPT, NT)                                                                                  \
   do {                                                                                                                 \
+    if (lds > 48 * 1024) {                                                                                             \
+      const void* fn = Gv < G ? (const void*)nb_sample_accumulate_kernel<VPT, NT, true>                                \
+                              : (const void*)nb_sample_accumulate_kernel<VPT, NT, false>;                              \
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {               \
+        cradle_set_error("nb_sample: cannot reserve %zu bytes of LDS for the deferred-draw queue", lds);               \
+        return CRADLE_ERR_HIP;                                                                                         \
+      }                                                                                                                \
+    }                                                                                                                  \
     if (Gv < G)                                                                                                        \
-      hipLaunchKernelGGL((nb_sample_accumulate_kernel<VPT, true>), dim3(C, splits), dim3(256), 0, stream, logits,      \
+      hipLaunchKernelGGL((nb_sample_accumulate_kernel<VPT, NT, true>), dim3(C, splits), dim3(NT), lds, stream, logits, \
                          ld_logits, library, library_n, gene_consts, sums, samples, P, C, G, method, sampler, lo, hi,  \
                          row_offset, partials, Gv);                                                                    \
     else                                                                                                               \
-      hipLaunchKernelGGL((nb_sample_accumulate_kernel<VPT, false>), dim3(C, splits), dim3(256), 0, stream, logits,     \
+      hipLaunchKernelGGL((nb_sample_accumulate_kernel<VPT, NT, false>), dim3(C, splits), dim3(NT), lds, stream, logits, \
                          ld_logits, library, library_n, gene_consts, sums, samples, P, C, G, method, sampler, lo, hi,  \
                          row_offset, partials, Gv);                                                                    \
   } while (0)
-  if (G4 <= 256) CRADLE_SAMPLE_LAUNCH(1);
-  else if (G4 <= 512) CRADLE_SAMPLE_LAUNCH(2);
-  else if (G4 <= 1024) CRADLE_SAMPLE_LAUNCH(4);
-  else if (G4 <= 1536) CRADLE_SAMPLE_LAUNCH(6);
-  else if (G4 <= 2048) CRADLE_SAMPLE_LAUNCH(8);
-  else if (G4 <= 4096) CRADLE_SAMPLE_LAUNCH(16);
-  else {
-    cradle_set_error("nb_sample: n_genes=%d exceeds the supported maximum 16384", G);
+  int nt = g_sample_tune_nt > 0 ? g_sample_tune_nt : (G4 <= 512 ? 256 : (G4 <= 1024 ? 512 : 1024));
+  const int vpt = (G4 + nt - 1) / nt;
+  const size_t lds = sampler == 0 ? (size_t)G * 8 : 0;  // slot[G] + queue[G]; the mean needs neither
+  bool launched = true;
+  if (nt == 256 && vpt == 1) CRADLE_SAMPLE_LAUNCH(1, 256);
+  else if (nt == 256 && vpt == 2) CRADLE_SAMPLE_LAUNCH(2, 256);
+  else if (nt == 256 && vpt <= 4) CRADLE_SAMPLE_LAUNCH(4, 256);
+  else if (nt == 256 && vpt <= 8) CRADLE_SAMPLE_LAUNCH(8, 256);
+  else if (nt == 512 && vpt == 1) CRADLE_SAMPLE_LAUNCH(1, 512);
+  else if (nt == 512 && vpt == 2) CRADLE_SAMPLE_LAUNCH(2, 512);
+  else if (nt == 512 && vpt == 3) CRADLE_SAMPLE_LAUNCH(3, 512);
+  else if (nt == 512 && vpt == 4) CRADLE_SAMPLE_LAUNCH(4, 512);
+  else if (nt == 1024 && vpt == 1) CRADLE_SAMPLE_LAUNCH(1, 1024);
+  else if (nt == 1024 && vpt == 2) CRADLE_SAMPLE_LAUNCH(2, 1024);
+  else if (nt == 1024 && vpt == 3) CRADLE_SAMPLE_LAUNCH(3, 1024);
+  else if (nt == 1024 && vpt == 4) CRADLE_SAMPLE_LAUNCH(4, 1024);
+  else launched = false;
+  if (!launched) {
+    cradle_set_error("nb_sample: n_genes=%d not supported with %d threads (maximum 16384 genes)", Gv, nt);
     return CRADLE_ERR_UNSUPPORTED;
   }
 #undef CRADLE_SAMPLE_LAUNCH

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "cradle_nb_workspace_floats": (i64, [i32, i32, i32]),
     "cradle_nb_particle_split": (i32, [i32, i32]),
     "cradle_nb_tune": (None, [i32, i32]),
+    "cradle_nb_sample_tune": (None, [i32]),
     "cradle_gemm_f32": (i32, [ctypes.c_void_p, c_float_p, i64, c_stream]),
     "cradle_gemm_workspace_floats": (i64, [i32, i32, i32, i32, i32]),
     "cradle_gemm_tune": (None, [i32, i32, i32, i32, i32, i32]),

@@ -108,6 +108,7 @@ int cradle_nb_logprob_fwd_bwd_static(const float* logits, int64_t ld_logits, flo
 int64_t cradle_nb_static_scratch_floats(void);
 /* tuning hook for tools/bench_nb.py: threads per workgroup (256/512/1024), particle split; -1 = auto */
 void cradle_nb_tune(int threads, int particle_split);
+void cradle_nb_sample_tune(int threads); /* same for K9 below: 256 / 512 / 1024 threads per workgroup, -1 = automatic */
 
 /* ---- K6: fp32 matrix-core GEMM with fused MLP epilogues ---------------------------------
  * Replaces torch.nn.Linear (+ LeakyReLU + residual) of cradle_vae/models/utils/mlp.py:76-80,
