@@ -241,6 +241,27 @@ def _mat(t: torch.Tensor):
 
 
 PRECISIONS = {"f32": 0, "bf16x3": 1}
+_default_precision = "f32"
+
+
+class gemm_precision:
+    """``with ops.gemm_precision("bf16x3"):`` -- the module path's GEMMs (guide / model / predictor: ATE, IWELBO) of
+    >= 1 GFLOP run in the optional split-bf16 mode inside the block (``cradle_gemm_desc.precision``); the fused training
+    step has its own switch (``loss_module.precision``).  Default "f32": the reference's arithmetic."""
+
+    def __init__(self, precision: str):
+        if precision not in PRECISIONS:
+            raise KeyError(precision)
+        self.precision = precision
+
+    def __enter__(self):
+        global _default_precision
+        self.previous, _default_precision = _default_precision, self.precision
+        return self
+
+    def __exit__(self, *exc):
+        global _default_precision
+        _default_precision = self.previous
 
 
 def gemm(
@@ -249,7 +270,7 @@ def gemm(
     residual: Optional[torch.Tensor] = None, dact_src: Optional[torch.Tensor] = None,
     out2: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None, rowbias_mode: int = 0,
     rowbias_n: int = 0, rowscale: Optional[torch.Tensor] = None, extra_col: Optional[torch.Tensor] = None,
-    workspace: Optional[torch.Tensor] = None, repeat: int = 1, precision: str = "f32", k_valid: int = 0,
+    workspace: Optional[torch.Tensor] = None, repeat: int = 1, precision: Optional[str] = None, k_valid: int = 0,
 ) -> torch.Tensor:
     """fp32 MFMA GEMM with the fused epilogue of ``cradle_gemm_f32`` (see the header).
     ``repeat`` > 1 relaunches the same GEMM from C (benchmarking aid).  ``precision``: "f32" (exact fp32 MFMA) or
@@ -278,7 +299,7 @@ def gemm(
     d.B, d.ldb = _mat(B)
     d.C, d.ldc = _mat(out)
     d.beta, d.act = beta, int(act)
-    d.precision = PRECISIONS[precision]
+    d.precision = PRECISIONS[_default_precision if precision is None else precision]
     d.k_valid = k_valid
     d.bias = hip.ptr(bias)
     if rowbias is not None:

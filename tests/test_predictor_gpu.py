@@ -426,3 +426,26 @@ def test_ate_with_ten_thousand_treatments_fits_in_two_gigabytes():
     extra = torch.cuda.max_memory_allocated() - base
     assert res.X.shape == (n_alt, G) and np.isfinite(res.X).all() and np.abs(res.X).max() > 0
     assert extra < 2 * 1024**3, f"{extra / 1024**3:.2f} GiB beyond the module"
+
+
+def test_ate_in_the_split_bf16_gemm_mode_stays_within_tolerance():
+    """`with ops.gemm_precision("bf16x3")`: the predictor's large GEMMs (here the decoder's output layer, 2688 x 5000 x
+    400 = 10.8 GFLOP per chunk) run on the split-bf16 kernels; the effects move by ~1e-5 of their scale (bar: 1e-4,
+    north_star's ELBO tolerance), and the mode really is taken (the results are not bit-identical)."""
+    from cradle_vae_amd import ops
+    from cradle_vae_amd.predictor import cradle_vae_Predictor
+
+    T, G, L, H, n_alt, c = 32, 5000, 16, 400, 20, 128
+    cfg, params, D_ctl, D_alt = _ate_setup(T, G, L, H, n_alt, seed=11)
+    lm = build_loss_module(dict(cfg=cfg, params={k: v.to(DEV) for k, v in params.items()}))
+    pred = cradle_vae_Predictor(lm.model, lm.guide)
+    kw = dict(dosages_alt=D_alt, dosages_control=D_ctl, quality=torch.ones(1, 1), method="perturbseq", n_particles=c,
+              condition_values=dict(library_size=1e4 * torch.ones(1)), batch_size=c, sampler="mean", seed=3)
+    exact = pred.estimate_average_treatment_effects(**kw).X
+    with ops.gemm_precision("bf16x3"):
+        split = pred.estimate_average_treatment_effects(**kw).X
+    again = pred.estimate_average_treatment_effects(**kw).X
+    assert np.array_equal(exact, again)  # the switch is scoped
+    scale = float(np.abs(exact).max())
+    err = float(np.abs(split - exact).max())
+    assert 0 < err <= 1e-4 * scale, (err, scale)
