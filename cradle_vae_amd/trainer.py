@@ -174,8 +174,7 @@ class TrainStep:
             self._region_sumsq(a, self._my_regions, mine)
             all_sums = parallel.all_gather_small(mine, gw)
             self._adam_regions(a, self._my_regions, all_sums)
-            for (s, e) in self.buckets:
-                parallel.all_gather_inplace_(a.flat[s:e], rk, gw)
+            parallel.all_gather_inplace_many_([a.flat[s:e] for (s, e) in self.buckets], rk, gw)
         else:
             self._region_sumsq(a, self._all_regions, self.region_sums)
             self._adam_regions(a, self._all_regions, self.region_sums)

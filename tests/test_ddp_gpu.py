@@ -104,6 +104,10 @@ def _rccl_worker(port, overlap, out, sync="allreduce"):
         losses = [float(st(batch, n_particles=syn.MID.n_particles)) for _ in range(4)]
         dist.barrier()
         torch.cuda.synchronize()
+        if sync == "rs_ag":  # the four parameter all-gathers went out as one coalesced RCCL launch, not by the fallback
+            from cradle_vae_amd import parallel
+
+            assert parallel._COALESCE["ok"]
         out[(int(overlap), sync)] = (st.fused.arena.flat.detach().cpu().clone(), losses)
     finally:
         dist.destroy_process_group()
