@@ -369,7 +369,12 @@ def main():
             out["replogle_shape"] = secondary_shape("replogle", device, args)
             # optional arithmetic mode, a side number: the headline above is fp32 (the reference's precision)
             out["bf16x3"] = secondary_shape("norman", device, args, precision="bf16x3")
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and shape.n_treatments > 4096:
+            # the CPU restatement does what the reference does: a dense (T, T) one-hot through the embedding encoder
+            # and (P, T, L) tensors over every treatment -- minutes and tens of GB per step at T = 10 000
+            out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"not run: the reference's dense form at T={shape.n_treatments} treatments"}
+        elif not args.no_cpu_baseline and world == 1:
             if stepper.fused is not None:
                 rel, rel_terms = loss_parity(lm, shape, batch, device)
                 out["loss_rel_err_vs_oracle"] = rel
