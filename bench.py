@@ -53,6 +53,8 @@ def build(shape, device, seed):
     lm = cradle_vae_ELBOLossModule(model=model, guide=guide, beta=shape.beta).to(device)
     # what trainer.fit takes from the data set (data.TensorPerturbationDataset.max_dosages_per_cell)
     lm.max_dosages_per_cell = max(1, int((batch["D"] != 0).sum(1).max().item()))
+    # ... and what data.DeviceBatchLoader hands over with every batch: the distinct treatments in it
+    batch["treatments_present"] = int((batch["D"] != 0).any(dim=0).sum().item())
     return lm, batch
 
 
@@ -90,12 +92,21 @@ def measured_copy_gbs(device, mbytes=512, reps=10):
     return 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def gemm_flops_fwd(s, kmax=None):
+def treatment_slots(s, lm, batch):
+    """Length of the treatment axis the fused step evaluates for this batch: all T, or -- when fewer -- the bound
+    N * kmax, or the distinct treatments the loader counted, rounded up to 32 (cradle_step_desc.max_present)."""
+    slots = min(s.n_treatments, s.n_cells * lm.max_dosages_per_cell)
+    if batch.get("treatments_present") is not None:
+        slots = min(slots, max(32, (batch["treatments_present"] + 31) // 32 * 32))
+    return slots
+
+
+def gemm_flops_fwd(s, slots=None):
     """Forward MLP GEMM flops of one step in the minimal form of SURVEY 8(d) (2 flops per MAC); the
     embedding encoder is counted for the treatment slots the step evaluates."""
     N, P, G, T, L = s.n_cells, s.n_particles, s.n_phenos, s.n_treatments, s.n_latent
-    if kmax:
-        T = min(T, N * kmax)
+    if slots:
+        T = min(T, slots)
     He, Hd, Hm = s.basal_encoder_n_hidden, s.decoder_n_hidden, s.embedding_encoder_n_hidden
     f_enc = 2 * 2 * N * G * He + 3 * 2 * P * N * (2 * L * He + 2 * He * L)
     f_dec = 2 * P * N * (3 * L * Hd + Hd * Hd * max(s.decoder_n_layers, 1) + Hd * G)
@@ -120,7 +131,7 @@ def loss_parity(lm, shape, batch, device):
             noise=dev(n1), cf_noise=dev(n2))
     torch.cuda.synchronize()
     f64 = lambda d: {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in d.items()}
-    params, b = f64(lm.state_dict()), f64({k: v for k, v in batch.items() if k != "idx"})
+    params, b = f64(lm.state_dict()), f64({k: v for k, v in batch.items() if k != "idx" and torch.is_tensor(v)})
     with torch.no_grad():
         ref, ref_metrics, _ = co.elbo_loss(
             params, X=b["X"], D=b["D"], qc=b["qc"], cfX=b["cfX"], library_size=b["library_size"],
@@ -205,7 +216,7 @@ def secondary_shape(name, device, args, precision="f32"):
     dt = (time.perf_counter() - t0) / steps
     res = {"value": shape.n_cells / dt, "unit": "cells/s", "ms_per_step": dt * 1e3, "steps": steps,
            "workload": f"{shape.name}: N={shape.n_cells}, P={shape.n_particles}, G={shape.n_phenos}, "
-                       f"T={shape.n_treatments} ({min(shape.n_treatments, shape.n_cells * lm.max_dosages_per_cell)} "
+                       f"T={shape.n_treatments} ({treatment_slots(shape, lm, batch)} "
                        f"treatment slots), L={shape.n_latent}"}
     if precision != "f32":
         res["dtype"] = "bf16x3 (bf16 hi+lo operands, 3 products, fp32 accumulate) in the GEMMs of >= 1 GFLOP; f32 elsewhere"
@@ -329,7 +340,7 @@ def main():
         # MFMA side: minimal-form GEMM flops of the step (fwd+bwd = 3x fwd) over the whole
         # step time, against the dense fp32 matrix-core peak -- a lower bound on MFMA utilisation
         # while the GEMMs run, since the step time also holds every non-GEMM kernel.
-        gf = gemm_flops_fwd(shape, lm.max_dosages_per_cell) * 3
+        gf = gemm_flops_fwd(shape, treatment_slots(shape, lm, batch)) * 3
         mfma = {"flops_per_step": gf, "achieved": gf / (elapsed / args.steps) / 1e12, "peak": MFMA_F32_PEAK_TF,
                 "unit": "TFLOP/s", "frac": gf / (elapsed / args.steps) / 1e12 / MFMA_F32_PEAK_TF,
                 "note": "minimal-form MLP GEMM flops (SURVEY 8d) / whole step time; fp32 v_mfma_f32_32x32x2_f32"}
@@ -359,7 +370,7 @@ def main():
                             f"T={shape.n_treatments}, L={shape.n_latent}, H={shape.decoder_n_hidden}",
                 "step_impl": stepper.impl,
                 "decoder_variants_per_cell": V, "parallelism": f"dp{world}",
-                "treatment_slots": min(shape.n_treatments, N * lm.max_dosages_per_cell),
+                "treatment_slots": treatment_slots(shape, lm, batch),
                 "loss": float(loss),
             },
             "roofline": roofline,

@@ -19,7 +19,7 @@ extern "C" {
 
 const char* cradle_last_error(void) { return g_last_error; }
 
-int cradle_abi_version(void) { return 5; }
+int cradle_abi_version(void) { return 6; }
 
 // Layout of the descriptor structs as THIS library was compiled: out[0] = sizeof, out[1..] = offsetof of every
 // field in declaration order.  Returns the number of entries (or -1: unknown struct / buffer too small).
@@ -64,7 +64,7 @@ int cradle_struct_layout(const char* name, int64_t* out, int max_entries) {
     OFF(S, beta); OFF(S, alpha); OFF(S, compute_grads);
     OFF(S, out); OFF(S, flags); OFF(S, workspace); OFF(S, workspace_bytes);
     OFF(S, ev_k1_begin); OFF(S, ev_k1_end); OFF(S, ev_gemm_begin); OFF(S, ev_gemm_end); OFF(S, ev_bucket);
-    OFF(S, rng_seed_plated); OFF(S, rng_seed_local); OFF(S, rng_step); OFF(S, precision);
+    OFF(S, rng_seed_plated); OFF(S, rng_seed_local); OFF(S, rng_step); OFF(S, precision); OFF(S, max_present);
     return n;
   }
 #undef OFF

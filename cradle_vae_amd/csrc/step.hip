@@ -87,7 +87,8 @@ struct Work {
 // Slots of the compact treatment axis (kernels.h, DosagePlan): a batch of N cells with at most kmax
 // dosages each cannot hold more than N*kmax distinct treatments.
 int compact_slots(const cradle_step_desc& d) {
-  const int64_t bound = (int64_t)d.N * d.kmax;
+  int64_t bound = (int64_t)d.N * d.kmax;
+  if (d.max_present > 0 && d.max_present < bound) bound = d.max_present;  // the caller has counted (desc.max_present)
   return bound < d.T ? (int)bound : d.T;
 }
 
@@ -105,8 +106,12 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   const int64_t PN = (int64_t)P * N, PT = (int64_t)PP * Tc;
   w.plan.kmax = d.kmax;
   w.plan.Tc = Tc;
-  w.plan.tmap = Tc < T ? a.take<int>(Tc) : nullptr;
-  w.plan.tpos = Tc < T ? a.take<int>(T) : nullptr;
+  // (reserved whatever Tc is: the layout then only shrinks when desc.max_present lowers Tc below what the workspace
+  // was sized for)
+  int* tmap = a.take<int>(Tc);
+  int* tpos = a.take<int>(T);
+  w.plan.tmap = Tc < T ? tmap : nullptr;
+  w.plan.tpos = Tc < T ? tpos : nullptr;
   w.plan.ell_idx = a.take<int>((int64_t)N * d.kmax);
   w.plan.ell_val = a.take<float>((int64_t)N * d.kmax);
   w.plan.tcount = a.take<int>(T);
@@ -428,6 +433,7 @@ int check_desc(const cradle_step_desc& d) {
                    "elbo_step: all sizes must be positive");
   CRADLE_CHECK_ARG(d.G >= 4, "elbo_step: n_phenos=%d below 4", d.G);
   CRADLE_CHECK_ARG(d.kmax >= 1 && d.kmax <= 64, "elbo_step: kmax=%d out of range [1,64]", d.kmax);
+  CRADLE_CHECK_ARG(d.max_present >= 0, "elbo_step: max_present=%d is negative", d.max_present);
   const cradle_mlp_ptrs* ms[4] = {&d.emb, &d.qce, &d.enc, &d.dec};
   const cradle_mlp_ptrs* gs[4] = {&d.d_emb, &d.d_qce, &d.d_enc, &d.d_dec};
   for (int i = 0; i < 4; ++i) {

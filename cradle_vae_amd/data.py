@@ -253,12 +253,19 @@ class DeviceBatchLoader:
                     r = v.index_select(0, sl)
                     batch[k] = r if r.dtype == torch.float32 else r.to(torch.float32)
             batch["idx"] = idx_all[s:s + self.batch_size]
+            # distinct treatments in the batch: lets the fused step size its treatment axis by what is there
+            # (cradle_step_desc.max_present) instead of by N * kmax; a device scalar here, a host int at hand-over
+            batch["treatments_present"] = (batch["D"] != 0).any(dim=0).sum(dtype=torch.int32).reshape(1)
+            return batch
+
+        def resolve(batch, pinned=None):
+            batch["treatments_present"] = int((batch["treatments_present"] if pinned is None else pinned)[0])
             return batch
 
         starts = list(range(0, stop, self.batch_size))
         if self.device.type != "cuda" or not self.prefetch or not starts:
             for s in starts:
-                yield gather(s)
+                yield resolve(gather(s))
         else:
             # the gathers of batch i+1 (index_select, integer -> fp32, densified D: ~0.1 ms of small kernels) run on a
             # side stream while the consumer's stream works on batch i; the hand-over is one event per batch
@@ -270,20 +277,23 @@ class DeviceBatchLoader:
             def launch(s):
                 with torch.cuda.stream(side):
                     b = gather(s)
+                    pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    pinned.copy_(b["treatments_present"], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(side)
-                return b, ev
+                return b, ev, pinned
 
             nxt = launch(starts[0])
             for i in range(len(starts)):
-                batch, ev = nxt
+                batch, ev, pinned = nxt
                 nxt = launch(starts[i + 1]) if i + 1 < len(starts) else None
                 cur = torch.cuda.current_stream(self.device)
                 cur.wait_event(ev)
                 for t in batch.values():
                     if t.is_cuda:
                         t.record_stream(cur)  # allocated on the side stream, read on the consumer's
-                yield batch
+                ev.synchronize()  # (enqueued one batch ago: done long before the consumer gets here)
+                yield resolve(batch, pinned)
         if self.shuffle:
             self.epoch += 1
 

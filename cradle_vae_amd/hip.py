@@ -94,7 +94,7 @@ PROTOTYPES = {
 }
 
 MAX_LAYERS = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class MlpPtrs(ctypes.Structure):
@@ -127,7 +127,7 @@ class StepDesc(ctypes.Structure):
            ("workspace_bytes", i64), ("ev_k1_begin", ctypes.c_void_p), ("ev_k1_end", ctypes.c_void_p),
            ("ev_gemm_begin", ctypes.c_void_p), ("ev_gemm_end", ctypes.c_void_p), ("ev_bucket", ctypes.c_void_p * 3),
            ("rng_seed_plated", ctypes.c_uint64), ("rng_seed_local", ctypes.c_uint64), ("rng_step", ctypes.c_uint64),
-           ("precision", i32)]
+           ("precision", i32), ("max_present", i32)]
     )
 
 

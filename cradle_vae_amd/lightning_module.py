@@ -88,7 +88,7 @@ class PerturbationLightningModule(_Base):
 
     def _get_extra_condition_values(self, batch):
         """:81-88 -- everything but X and D rides along as a condition value."""
-        return {k: v for k, v in batch.items() if k not in ("X", "D")}
+        return {k: v for k, v in batch.items() if k not in ("X", "D", "treatments_present")}  # (the last: loader metadata)
 
     def _step(self, batch, split: str, test: bool):
         loss, metrics = self.loss_module.loss(

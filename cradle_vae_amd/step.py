@@ -248,8 +248,11 @@ class FusedElboStep:
 
     # ------------------------------------------------------------------ launch
     def run(self, *, X, D, D_obs_counts, qc, qc_obs_counts, cfX, library_size, n_particles, noise=None, cf_noise=None,
-            compute_grads=True, gen_plated=None, gen_local=None, rng_key=None):
-        """Launches the step; returns the (8,) device tensor [loss, 5 loss terms, cf KL, -]."""
+            compute_grads=True, gen_plated=None, gen_local=None, rng_key=None, treatments_present=None):
+        """Launches the step; returns the (8,) device tensor [loss, 5 loss terms, cf KL, -].  ``treatments_present``:
+        the number of distinct treatments with a non-zero dosage in ``D`` if the caller has counted them (a host
+        integer, e.g. ``DeviceBatchLoader``'s ``batch["treatments_present"]``): the treatment axis of the step is then
+        that long (rounded up to 32) instead of N*kmax -- cradle_step_desc.max_present."""
         if not self.arena.valid():
             self.arena.rebuild()  # e.g. after module.to(device) or load_state_dict(assign=True)
             self._states.clear()
@@ -266,6 +269,7 @@ class FusedElboStep:
         d.beta = float(self.lm.beta)
         d.alpha = -1.0 if self.lm.alpha is None else float(self.lm.alpha)
         d.compute_grads = int(compute_grads)
+        d.max_present = 0 if treatments_present is None else max(32, (int(treatments_present) + 31) & ~31)
         d.precision = {"f32": 0, "bf16x3": 1}[getattr(self.lm, "precision", "f32")]
         sample = self._calls % max(1, self.event_every) == 0
         if self.k1_events is not None and sample:
@@ -317,7 +321,10 @@ class FusedElboStep:
         if f:
             self.out[7] = 0.0
         if f & 1:
-            raise hip.CradleHipError(f"a cell has more than kmax={self.desc.kmax} non-zero dosages: raise kmax")
+            raise hip.CradleHipError(
+                f"a cell has more than kmax={self.desc.kmax} non-zero dosages (raise kmax)"
+                + (f", or the batch holds more distinct treatments than the {self.desc.max_present} slots it was "
+                   "announced with (treatments_present)" if self.desc.max_present else ""))
         if f & 2:
             raise hip.CradleHipError("qc has entries outside {0,1}: the fused step scores one decoder variant per cell; "
                                      "use loss_module.step = 'modular'")

@@ -123,8 +123,8 @@ class TrainStep:
         out = f.run(
             X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"],
             qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
-            n_particles=n_particles, **({"gen_plated": self.gen_plated, "gen_local": self.gen_local}
-                                         if self.rng == "torch" else {}))
+            n_particles=n_particles, treatments_present=batch.get("treatments_present"),
+            **({"gen_plated": self.gen_plated, "gen_local": self.gen_local} if self.rng == "torch" else {}))
         a = f.arena
         self.step_count += 1
         if self.world_size > 1:

@@ -256,6 +256,12 @@ typedef struct cradle_step_desc {
                              NULL = off */
   uint64_t rng_seed_plated, rng_seed_local, rng_step;   /* used when the noise pointers are NULL */
   int precision;          /* cradle_gemm_desc.precision for the step's GEMMs: 0 = fp32 (default), 1 = bf16x3 */
+  int max_present;        /* 0, or an upper bound on the number of DISTINCT treatments with a non-zero dosage in this
+                             batch, when the caller knows one below N*kmax (a loader that has looked at the batch):
+                             q(M), q(E|M) and the embedding encoder are evaluated on min(N*kmax, max_present, T) slots
+                             -- the reference evaluates all T (model.py:96-117, correlated_normal_guide.py:132-194);
+                             treatments absent from the batch contribute closed-form terms only.  A batch with more
+                             present treatments than slots raises bit 0 of *flags (nothing is mis-scored). */
 } cradle_step_desc;
 
 int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only the sizes are read */

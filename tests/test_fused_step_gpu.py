@@ -32,12 +32,7 @@ def test_fused_step_matches_reference(name):
     check_against_golden(case, loss, metrics, grads)
 
 
-@pytest.mark.parametrize("kmax,n_phenos", [(8, 1200), (2, 1200), (2, 1201)])
-def test_fused_equals_modular_at_replogle_like_shape(kmax, n_phenos):
-    """T > N, L = 100, two-layer-free encoder: sizes the golden fixtures do not reach.  kmax=2 (the
-    data set's true bound) makes N*kmax < T, i.e. the step runs q(M), q(E|M) on the compact axis of
-    treatments present in the batch; kmax=8 keeps the full axis.  n_phenos=1201: a gene count that is not a
-    multiple of 4 through both paths (the modular one hands K1 row-padded views of the logits and counts)."""
+def _replogle_like_case(n_phenos=1200):
     import dataclasses
 
     from cradle_vae_amd import synthetic as syn
@@ -55,6 +50,16 @@ def test_fused_equals_modular_at_replogle_like_shape(kmax, n_phenos):
                             log_x_mean=b["log_x_mean"].cpu(), log_x_std=b["log_x_std"].cpu(), seed=9)
     case = dict(cfg=cfg, params={k: v.to(DEV) for k, v in params.items()}, batch=b,
                 noise=syn.make_noise(shape, 1, DEV), cf_noise=syn.make_noise(shape, 2, DEV))
+    return case, cfg, b
+
+
+@pytest.mark.parametrize("kmax,n_phenos", [(8, 1200), (2, 1200), (2, 1201)])
+def test_fused_equals_modular_at_replogle_like_shape(kmax, n_phenos):
+    """T > N, L = 100, two-layer-free encoder: sizes the golden fixtures do not reach.  kmax=2 (the
+    data set's true bound) makes N*kmax < T, i.e. the step runs q(M), q(E|M) on the compact axis of
+    treatments present in the batch; kmax=8 keeps the full axis.  n_phenos=1201: a gene count that is not a
+    multiple of 4 through both paths (the modular one hands K1 row-padded views of the logits and counts)."""
+    case, cfg, b = _replogle_like_case(n_phenos)
     lm = build_loss_module(case)
     lm.max_dosages_per_cell = kmax
     loss_f, met_f, g_f = run_fused(lm, case)
@@ -77,6 +82,30 @@ def test_fused_equals_modular_at_replogle_like_shape(kmax, n_phenos):
         assert err < 2e-3, (k, err)
         l2 = float((g_f[k] - ref).norm()) / max(float(ref.norm()), 1e-12)
         assert l2 < 1e-4, (k, l2)
+
+
+def test_treatment_axis_sized_by_the_treatments_present():
+    """A loader that has counted the distinct treatments of a batch tells the step (cradle_step_desc.max_present): the
+    treatment axis of q(M), q(E|M) and the embedding encoder shrinks from N*kmax slots to that count (rounded up to 32)
+    and nothing else changes; announcing fewer than there are is reported, not mis-scored."""
+    from cradle_vae_amd import hip
+
+    case, cfg, b = _replogle_like_case()
+    lm = build_loss_module(case)
+    lm.max_dosages_per_cell = 2
+    fs = lm._fused_step()
+    out0, g0 = _step_outputs(fs, case)
+    assert fs.desc.max_present == 0
+    n = int((b["D"] != 0).any(dim=0).sum())
+    assert 64 < n < 160  # 96 cells x <= 2 dosages: far fewer distinct treatments than the 192 slots of the bound
+    out1, g1 = _step_outputs(fs, case, treatments_present=n)
+    assert fs.desc.max_present == (n + 31) // 32 * 32 < 192
+    assert torch.allclose(out1[:7], out0[:7], rtol=2e-6, atol=1e-6)
+    assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max())
+    fs.check_flags()
+    _step_outputs(fs, case, treatments_present=33)  # 64 slots for more than 64 treatments
+    with pytest.raises(hip.CradleHipError, match="treatments_present"):
+        fs.check_flags()
 
 
 def test_compact_axis_overflow_is_reported():

@@ -182,8 +182,10 @@ def test_sparse_dosage_and_packed_counts_give_the_dense_loaders_batches():
     assert b.stored_bytes() < 0.5 * a.stored_bytes()
     for x, y in zip(a, b):
         assert set(x) == set(y)
+        assert x["treatments_present"] == y["treatments_present"] == int((x["D"] != 0).any(0).sum())  # a host int
         for k in x:
-            assert x[k].dtype == y[k].dtype and torch.equal(x[k], y[k]), k
+            if k != "treatments_present":
+                assert x[k].dtype == y[k].dtype and torch.equal(x[k], y[k]), k
     # the in-memory data module keeps D sparse throughout
     names = ["ctl" if not r.any() else "+".join(f"g{j}" for j in torch.nonzero(r).squeeze(1).tolist()) for r in D]
     splits = np.where(np.arange(n) % 5 == 0, "val", np.where(np.arange(n) % 7 == 0, "test", "train"))
@@ -331,7 +333,7 @@ def test_synthetic_data_module_interface():
     ate = dm.get_estimated_average_treatment_effects("mean")
     assert ate.X.shape == (len(names), 24) and ate.uns["control"] == "non-targeting"
     b = next(iter(dm.train_dataloader()))
-    assert set(b) == {"X", "D", "qc", "cfX", "library_size", "idx"} and b["X"].shape == (50, 24)
+    assert set(b) == {"X", "D", "qc", "cfX", "library_size", "idx", "treatments_present"} and b["X"].shape == (50, 24)
 
 
 def test_max_dosages_per_cell_reaches_the_loss_module():
