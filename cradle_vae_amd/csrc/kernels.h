@@ -102,6 +102,8 @@ int cell_prep(const float* qc, const float* D_obs, const float* qc_obs, const in
               int N, int T, int Q, const CellPrep& out, int* flags, int Tc, const int* tmap, hipStream_t stream);
 
 // u_mask, eps_E (n_mask each), eps_qc_E (n_qc), eps_z (n_z): Philox draws keyed by (seed, step)
+int draw_noise_slots(float* u_mask, float* eps_E, const int* tmap, int PP, int T, int Tc, int L, uint64_t seed_plated,
+                     uint64_t step, hipStream_t stream);
 int draw_noise(float* u_mask, float* eps_E, float* eps_qc_E, float* eps_z, int64_t n_mask, int64_t n_qc, int64_t n_z,
                uint64_t seed_plated, uint64_t seed_local, uint64_t step, int which, hipStream_t stream);
 

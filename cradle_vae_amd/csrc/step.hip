@@ -556,9 +556,12 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, Tc, w.plan.tmap,
                  s1));
   // the step's own noise: q(qc_E)'s on the stream that reads it, the rest on the caller's -- no event between them
+  // Compact treatment axis: u_mask / eps_E are (2P, T, L), but only the rows of the treatments in the batch are ever
+  // read -- those are drawn once the slot map exists (below), the same values at the same places
+  const bool slot_noise = own_noise && w.plan.tmap && L % 4 == 0;
   if (own_noise) {
     STEP(draw_noise(w.u_mask, w.eps_E, w.eps_qc_E, w.eps_z, (int64_t)PP * T * L, (int64_t)PP * Q * L, (int64_t)PN * L,
-                    d.rng_seed_plated, d.rng_seed_local, d.rng_step, 1 | 2 | 8, s));
+                    d.rng_seed_plated, d.rng_seed_local, d.rng_step, slot_noise ? 8 : (1 | 2 | 8), s));
     STEP(draw_noise(w.u_mask, w.eps_E, w.eps_qc_E, w.eps_z, (int64_t)PP * T * L, (int64_t)PP * Q * L, (int64_t)PN * L,
                     d.rng_seed_plated, d.rng_seed_local, d.rng_step, 4, s2));
   }
@@ -585,6 +588,8 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   hipEvent_t ev_s2 = c.record(2);
 
   if (w.plan.tmap) c.wait(0, ev_plan);
+  if (slot_noise)
+    STEP(draw_noise_slots(w.u_mask, w.eps_E, w.plan.tmap, PP, T, Tc, L, d.rng_seed_plated, d.rng_step, s));
   PROBE(1);
   STEP(mask_fwd(d.q_mask_logits, nz_u, d.p_mask_probs, d.temperature, w.mask, w.soft, w.Smask, PP, T, Tc, w.plan.tmap,
                 L, s));

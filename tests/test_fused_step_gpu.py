@@ -108,6 +108,28 @@ def test_treatment_axis_sized_by_the_treatments_present():
         fs.check_flags()
 
 
+def test_compact_axis_draws_only_the_noise_it_reads():
+    """The step's own draws on the compact axis: u_mask / eps_E are drawn for the treatments in the batch only, once the
+    slot map exists -- the same values as the full draw (keyed by treatment, not by slot): same key, same loss and
+    gradients whether the axis is compact (kmax = 2: 192 slots of 700), counted (treatments_present) or full."""
+    case, cfg, b = _replogle_like_case()
+    outs = []
+    for kmax, count in ((8, None), (2, None), (2, int((b["D"] != 0).any(dim=0).sum()))):
+        lm = build_loss_module(case)
+        lm.max_dosages_per_cell = kmax
+        fs = lm._fused_step()
+        out = fs.run(X=b["X"], D=b["D"], D_obs_counts=b["D_obs_counts"], qc=b["qc"], qc_obs_counts=b["qc_obs_counts"],
+                     cfX=b["cfX"], library_size=b["library_size"], n_particles=cfg["n_particles"], rng_key=(11, 12, 5),
+                     treatments_present=count)
+        torch.cuda.synchronize()
+        assert (fs.desc.N * fs.desc.kmax < fs.desc.T) == (kmax == 2) and fs.desc.u_mask is None
+        outs.append((out.clone(), fs.arena.grad.clone()))
+    for out, g in outs[1:]:
+        assert torch.isfinite(out[:7]).all()
+        assert torch.allclose(out[:7], outs[0][0][:7], rtol=2e-6, atol=1e-6)
+        assert float((g - outs[0][1]).abs().max()) <= 1e-5 * float(outs[0][1].abs().max())
+
+
 def test_compact_axis_overflow_is_reported():
     """More non-zero dosages in a cell than the declared bound: the step must say so, not mis-score."""
     import dataclasses
