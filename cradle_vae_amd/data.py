@@ -274,10 +274,15 @@ class DeviceBatchLoader:
             side = self._side
             side.wait_stream(torch.cuda.current_stream(self.device))  # storage and pos_dev were made there
 
+            if getattr(self, "_pinned", None) is None:  # two batches are in flight at most: a ring of four host words
+                self._pinned = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(4)]
+            ring = [0]
+
             def launch(s):
                 with torch.cuda.stream(side):
                     b = gather(s)
-                    pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    pinned = self._pinned[ring[0] % 4]
+                    ring[0] += 1
                     pinned.copy_(b["treatments_present"], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(side)
