@@ -19,7 +19,7 @@ extern "C" {
 
 const char* cradle_last_error(void) { return g_last_error; }
 
-int cradle_abi_version(void) { return 6; }
+int cradle_abi_version(void) { return 7; }
 
 // Layout of the descriptor structs as THIS library was compiled: out[0] = sizeof, out[1..] = offsetof of every
 // field in declaration order.  Returns the number of entries (or -1: unknown struct / buffer too small).
@@ -38,6 +38,14 @@ int cradle_struct_layout(const char* name, int64_t* out, int max_entries) {
     typedef cradle_mlp_ptrs S;
     PUT(sizeof(S));
     OFF(S, n_layers); OFF(S, W); OFF(S, b); OFF(S, W_head); OFF(S, b_head);
+    return n;
+  }
+  if (!strcmp(name, "cradle_batch_desc")) {
+    typedef cradle_batch_desc S;
+    PUT(sizeof(S));
+    OFF(S, N); OFF(S, G); OFF(S, T); OFF(S, Q); OFF(S, kmax); OFF(S, x_type); OFF(S, cfx_type); OFF(S, pos); OFF(S, X);
+    OFF(S, cfX); OFF(S, qc); OFF(S, library_size); OFF(S, d_idx); OFF(S, d_val); OFF(S, d_dense); OFF(S, X_out);
+    OFF(S, cfX_out); OFF(S, qc_out); OFF(S, lib_out); OFF(S, D_out); OFF(S, present_out);
     return n;
   }
   if (!strcmp(name, "cradle_gemm_desc")) {

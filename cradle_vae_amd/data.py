@@ -202,6 +202,46 @@ class DeviceBatchLoader:
                        qc=take(dataset.qc).to(**f32), cfX=pack_counts(take(dataset.cfX), count_dtype).to(self.device),
                        library_size=take(dataset.library_size).to(**f32))
 
+    _COUNT_TYPES = {torch.float32: 0, torch.uint8: 1, torch.int16: 2, torch.int32: 3}
+
+    @property
+    def _hip_ok(self) -> bool:
+        t = self._t
+        T = t["D"].n_treatments if isinstance(t["D"], SparseDosage) else t["D"].shape[1]
+        return (t["X"].dtype in self._COUNT_TYPES and t["cfX"].dtype in self._COUNT_TYPES and T <= 60 * 1024 * 8
+                and all(v.is_contiguous() for v in (t["X"], t["cfX"], t["qc"], t["library_size"]))
+                and (isinstance(t["D"], SparseDosage) or (t["D"].is_contiguous() and t["D"].dtype == torch.float32))
+                and t["qc"].dtype == torch.float32 and t["library_size"].dtype == torch.float32)
+
+    def _gather_hip(self, sl: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """The batch of stored rows ``sl`` through ``cradle_gather_batch`` (csrc/batch.hip)."""
+        import ctypes
+
+        from . import hip
+
+        t, dev = self._t, self.device
+        N, G, Q = sl.numel(), t["X"].shape[1], t["qc"].shape[1]
+        sparse = isinstance(t["D"], SparseDosage)
+        T = t["D"].n_treatments if sparse else t["D"].shape[1]
+        f32 = dict(device=dev, dtype=torch.float32)
+        out = dict(X=torch.empty((N, G), **f32), D=torch.empty((N, T), **f32), qc=torch.empty((N, Q), **f32),
+                   cfX=torch.empty((N, G), **f32), library_size=torch.empty((N,), **f32),
+                   treatments_present=torch.empty((1,), device=dev, dtype=torch.int32))
+        d = hip.BatchDesc()
+        d.N, d.G, d.T, d.Q = N, G, T, Q
+        d.x_type, d.cfx_type = self._COUNT_TYPES[t["X"].dtype], self._COUNT_TYPES[t["cfX"].dtype]
+        d.pos, d.X, d.cfX = sl.data_ptr(), t["X"].data_ptr(), t["cfX"].data_ptr()
+        d.qc, d.library_size = t["qc"].data_ptr(), t["library_size"].data_ptr()
+        if sparse:
+            d.kmax, d.d_idx, d.d_val = t["D"].idx.shape[1], t["D"].idx.data_ptr(), t["D"].val.data_ptr()
+        else:
+            d.d_dense = t["D"].data_ptr()
+        d.X_out, d.cfX_out, d.qc_out = out["X"].data_ptr(), out["cfX"].data_ptr(), out["qc"].data_ptr()
+        d.lib_out, d.D_out, d.present_out = (out["library_size"].data_ptr(), out["D"].data_ptr(),
+                                             out["treatments_present"].data_ptr())
+        hip.check(hip.load().cradle_gather_batch(ctypes.byref(d), hip.stream()), "cradle_gather_batch")
+        return out
+
     def set_epoch(self, epoch: int):
         self.epoch = epoch
 
@@ -245,6 +285,10 @@ class DeviceBatchLoader:
 
         def gather(s):
             sl = pos_dev[s:s + self.batch_size]
+            if self.device.type == "cuda" and self._hip_ok:
+                batch = self._gather_hip(sl)  # K0: one launch for the five tensors, one for the count
+                batch["idx"] = idx_all[s:s + self.batch_size]
+                return batch
             batch = {}
             for k, v in self._t.items():
                 if isinstance(v, SparseDosage):

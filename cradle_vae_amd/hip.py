@@ -24,6 +24,7 @@ i32, i64 = ctypes.c_int, ctypes.c_int64
 PROTOTYPES = {
     "cradle_last_error": (ctypes.c_char_p, []),
     "cradle_abi_version": (i32, []),
+    "cradle_gather_batch": (i32, [ctypes.c_void_p, c_stream]),
     "cradle_device_count": (i32, []),
     "cradle_struct_layout": (i32, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), i32]),
     "cradle_event_create": (i32, [ctypes.POINTER(ctypes.c_void_p)]),
@@ -94,7 +95,7 @@ PROTOTYPES = {
 }
 
 MAX_LAYERS = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class MlpPtrs(ctypes.Structure):
@@ -128,6 +129,16 @@ class StepDesc(ctypes.Structure):
            ("ev_gemm_begin", ctypes.c_void_p), ("ev_gemm_end", ctypes.c_void_p), ("ev_bucket", ctypes.c_void_p * 3),
            ("rng_seed_plated", ctypes.c_uint64), ("rng_seed_local", ctypes.c_uint64), ("rng_step", ctypes.c_uint64),
            ("precision", i32), ("max_present", i32)]
+    )
+
+
+class BatchDesc(ctypes.Structure):
+    """struct cradle_batch_desc (include/cradle_hip.h); field order is ABI."""
+
+    _fields_ = (
+        [(k, i32) for k in ("N", "G", "T", "Q", "kmax", "x_type", "cfx_type")]
+        + [(k, ctypes.c_void_p) for k in ("pos", "X", "cfX", "qc", "library_size", "d_idx", "d_val", "d_dense", "X_out",
+                                          "cfX_out", "qc_out", "lib_out", "D_out", "present_out")]
     )
 
 
@@ -179,7 +190,8 @@ def load() -> ctypes.CDLL:
     if lib.cradle_abi_version() != ABI_VERSION:
         raise CradleHipError(f"{_LIB_PATH} has ABI version {lib.cradle_abi_version()}, this binding expects "
                              f"{ABI_VERSION}: rebuild it (make -C cradle_vae_amd/csrc)")
-    for cname, cls in (("cradle_mlp_ptrs", MlpPtrs), ("cradle_gemm_desc", GemmDesc), ("cradle_step_desc", StepDesc)):
+    for cname, cls in (("cradle_mlp_ptrs", MlpPtrs), ("cradle_gemm_desc", GemmDesc), ("cradle_step_desc", StepDesc),
+                       ("cradle_batch_desc", BatchDesc)):
         mine, theirs = struct_layout(cls), library_struct_layout(lib, cname)
         if mine != theirs:
             raise CradleHipError(f"layout of {cname} differs between include/cradle_hip.h as compiled "

@@ -305,6 +305,35 @@ int cradle_adam_step_regions(float* params, const float* grads, float* exp_avg, 
                              float max_norm, float grad_scale, float* norm_out, const int* skip_flags,
                              cradle_stream_t stream);
 
+/* ---- K0: batch gather of the device-resident data source ------------------------------------
+ * Replaces the DataLoader over TensorPerturbationDataset / SCRNASeqTensorPerturbationDataset
+ * (cradle_vae/data/utils/perturbation_dataset.py:44-89: X[idx], D[idx], qc[idx], cfX[idx], library_size[idx] as fp32,
+ * collated on the host, copied to the device every step).  The data set stays on the GPU in compact form -- counts as
+ * uint8 / int16 / int32 (integer-valued, converted exactly), D as <= kmax (treatment, dosage) pairs per cell (index
+ * -1 = unused) or dense -- and one launch gathers the rows pos[0..N) into the dense fp32 tensors of the batch contract.
+ * present_out (may be NULL): receives (D_out != 0).any(0).sum(), the number of distinct treatments in the batch
+ * (cradle_step_desc.max_present; needs n_treatments <= 491 520). */
+enum { CRADLE_COUNTS_F32 = 0, CRADLE_COUNTS_U8 = 1, CRADLE_COUNTS_I16 = 2, CRADLE_COUNTS_I32 = 3 };
+typedef struct cradle_batch_desc {
+  int N, G, T, Q, kmax;          /* batch rows, genes, treatments, qc columns, pairs per cell (sparse D) */
+  int x_type, cfx_type;          /* CRADLE_COUNTS_* of the stored X / cfX */
+  const int64_t* pos;            /* (N) rows of the stored tensors to gather (device) */
+  const void* X;                 /* (rows, G) */
+  const void* cfX;               /* (rows, G) */
+  const float* qc;               /* (rows, Q) */
+  const float* library_size;     /* (rows) */
+  const int* d_idx;              /* (rows, kmax) or NULL */
+  const float* d_val;            /* (rows, kmax) or NULL */
+  const float* d_dense;          /* (rows, T) or NULL: exactly one of the two forms */
+  float* X_out;                  /* (N, G) */
+  float* cfX_out;                /* (N, G) */
+  float* qc_out;                 /* (N, Q) */
+  float* lib_out;                /* (N) */
+  float* D_out;                  /* (N, T) */
+  int* present_out;              /* (1) or NULL */
+} cradle_batch_desc;
+int cradle_gather_batch(const cradle_batch_desc* desc, cradle_stream_t stream);
+
 /* ---- K9: Gamma-Poisson observation sampler fused with the ATE accumulation ---------------
  * Replaces, per (particle p, condition t) row r = p*C + t of decoder logits:
  *   mlp.py:153-166 (softmax -> mu -> rate) + pyro GammaPoisson.sample at model.py:131

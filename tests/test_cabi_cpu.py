@@ -33,7 +33,7 @@ def test_descriptor_layouts_agree_between_header_library_and_binding():
     text = open(os.path.join(ROOT, "include", "cradle_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     for cname, cls in (("cradle_mlp_ptrs", hip.MlpPtrs), ("cradle_gemm_desc", hip.GemmDesc),
-                       ("cradle_step_desc", hip.StepDesc)):
+                       ("cradle_step_desc", hip.StepDesc), ("cradle_batch_desc", hip.BatchDesc)):
         mine, theirs = hip.struct_layout(cls), hip.library_struct_layout(lib, cname)
         assert mine == theirs, (cname, mine, theirs)
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
