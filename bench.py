@@ -219,7 +219,8 @@ def secondary_shape(name, device, args, precision="f32"):
                        f"T={shape.n_treatments} ({treatment_slots(shape, lm, batch)} "
                        f"treatment slots), L={shape.n_latent}"}
     if precision != "f32":
-        res["dtype"] = "bf16x3 (bf16 hi+lo operands, 3 products, fp32 accumulate) in the GEMMs of >= 1 GFLOP; f32 elsewhere"
+        res["dtype"] = ("bf16x3 (bf16 hi+lo operands, 3 products, fp32 accumulate)" if precision == "bf16x3" else
+                        "bf16 (operands rounded to bf16, fp32 accumulate)") + " in the GEMMs of >= 1 GFLOP; f32 elsewhere"
         if not args.no_cpu_baseline:
             res["loss_rel_err_vs_oracle"], res["loss_terms_max_rel_err_vs_oracle"] = loss_parity(lm, shape, batch, device)
     return res
@@ -380,6 +381,7 @@ def main():
             out["replogle_shape"] = secondary_shape("replogle", device, args)
             # optional arithmetic mode, a side number: the headline above is fp32 (the reference's precision)
             out["bf16x3"] = secondary_shape("norman", device, args, precision="bf16x3")
+            out["bf16"] = secondary_shape("norman", device, args, precision="bf16")
         if not args.no_cpu_baseline and world == 1 and shape.n_treatments > 4096:
             # the CPU restatement does what the reference does: a dense (T, T) one-hot through the embedding encoder
             # and (P, T, L) tensors over every treatment -- minutes and tens of GB per step at T = 10 000

@@ -411,7 +411,7 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
   if (layout == 0) aligned = aligned && p.K % 4 == 0;
   else if (layout == 1) aligned = aligned && p.K % 4 == 0 && row_ok(p.N, p.ldb);
   else aligned = aligned && row_ok(p.M, p.lda) && row_ok(p.N, p.ldb);
-  if (p.precision == 1 && aligned && flops >= 1.0e9) {
+  if (p.precision >= 1 && aligned && flops >= 1.0e9) {
     // split-bf16 kernels: 128 x 128 tiles, 64 in a dimension that pads less that way (400 -> 448 instead of 512);
     // two to four workgroups per CU, so aim at ~1024 of them (tools/bench_bf16x3.py), never below 8 K-steps per split
     auto padded = [](int n, int t) { return (n + 64 * t - 1) / (64 * t) * (64 * t); };
@@ -477,7 +477,8 @@ int cradle_gemm_f32(const cradle_gemm_desc* d, float* workspace, int64_t workspa
   p.act = d->act; p.act_out = d->act_out; p.ld_act = d->ld_act_out;
   p.res = d->residual; p.ld_res = d->ld_residual; p.dact_src = d->dact_src; p.ld_ds = d->ld_dact_src;
   p.C2 = d->C2; p.ldc2 = d->ldc2; p.extra_col = d->extra_col;
-  CRADLE_CHECK_ARG(d->precision == 0 || d->precision == 1, "gemm: precision must be 0 (fp32) or 1 (bf16x3), got %d", d->precision);
+  CRADLE_CHECK_ARG(d->precision >= 0 && d->precision <= 2, "gemm: precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16), got %d",
+                   d->precision);
   p.precision = d->precision;
   CRADLE_CHECK_ARG(d->k_valid >= 0 && d->k_valid <= d->K, "gemm: k_valid=%d outside [0, K=%d]", d->k_valid, d->K);
   p.k_valid = d->k_valid;

@@ -84,6 +84,8 @@ struct SplitLoader {
   }
 
   // ones_row >= 0 (MN-major B of a weight gradient only): logical row whose value is 1 for every k < kdim.
+  // SPLIT = false (plain bf16 mode): only the rounded values are staged
+  template <bool SPLIT = true>
   __device__ __forceinline__ void store(u32x4* __restrict__ hi_plane, u32x4* __restrict__ lo_plane, int row0, int k0,
                                         int kdim, int ones_row) const {
     if (KMAJOR) {
@@ -102,7 +104,7 @@ struct SplitLoader {
         }
         const int s = slot_of(c4 / 2, r, ROWS);
         reinterpret_cast<u32x2*>(hi_plane + s)[c4 & 1] = __builtin_bit_cast(u32x2, h);
-        reinterpret_cast<u32x2*>(lo_plane + s)[c4 & 1] = __builtin_bit_cast(u32x2, l);
+        if (SPLIT) reinterpret_cast<u32x2*>(lo_plane + s)[c4 & 1] = __builtin_bit_cast(u32x2, l);
       }
     } else {
 #pragma unroll
@@ -125,13 +127,15 @@ struct SplitLoader {
         }
         const int s = slot_of(c, r, ROWS);
         hi_plane[s] = __builtin_bit_cast(u32x4, h);
-        lo_plane[s] = __builtin_bit_cast(u32x4, l);
+        if (SPLIT) lo_plane[s] = __builtin_bit_cast(u32x4, l);
       }
     }
   }
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, int TM, int TN>
+// SPLIT = true: three products per element pair (bf16x3, ~fp32 accuracy); false: one product of the rounded operands
+// (plain bf16 inputs, fp32 accumulation: ~3 significant digits per product)
+template <bool A_KMAJOR, bool B_KMAJOR, int TM, int TN, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmParams p) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   using LA = SplitLoader<A_KMAJOR, BM>;
@@ -193,8 +197,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmParams p) {
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       const int cur = st;
-      la[st].store(Ahi(cur), Alo(cur), row0, (kt + st) * kBK, k_limit, -1);
-      lb[st].store(Bhi(cur), Blo(cur), col0, (kt + st) * kBK, k_limit, ones_b);
+      la[st].template store<SPLIT>(Ahi(cur), Alo(cur), row0, (kt + st) * kBK, k_limit, -1);
+      lb[st].template store<SPLIT>(Bhi(cur), Blo(cur), col0, (kt + st) * kBK, k_limit, ones_b);
       la[st].load(p.A, p.lda, p.a_bytes, row0, (kt + st + 2) * kBK, p.M, k_limit);
       lb[st].load(p.B, p.ldb, p.b_bytes, col0, (kt + st + 2) * kBK, p.N, k_limit);
       __syncthreads();
@@ -206,20 +210,22 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmParams p) {
         for (int i = 0; i < TM; ++i) {
           const int s = slot_of(c, (wm * TM + i) * 32 + li, BM);
           ah[i] = __builtin_bit_cast(bf16x8, Ahi(cur)[s]);
-          al[i] = __builtin_bit_cast(bf16x8, Alo(cur)[s]);
+          if (SPLIT) al[i] = __builtin_bit_cast(bf16x8, Alo(cur)[s]);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int s = slot_of(c, (wn * TN + j) * 32 + li, BN);
           bh[j] = __builtin_bit_cast(bf16x8, Bhi(cur)[s]);
-          bl[j] = __builtin_bit_cast(bf16x8, Blo(cur)[s]);
+          if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8, Blo(cur)[s]);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            if (SPLIT) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           }
       }
@@ -262,15 +268,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmParams p) {
 }
 
 // Launch for a prepared GemmParams (splitk, slab, partial, a_bytes, b_bytes filled by gemm_f32).
-bool launch_gemm_bf16x3(int layout, const GemmParams& p, int tm, int tn, hipStream_t s) {
+template <bool SPLIT>
+static bool launch_split(int layout, const GemmParams& p, int tm, int tn, hipStream_t s) {
   const int Np = p.N + (p.extra_col ? 1 : 0);
   const int bm = 64 * tm, bn = 64 * tn;
   dim3 grid((unsigned)(((p.M + bm - 1) / bm) * ((Np + bn - 1) / bn)), 1, (unsigned)p.splitk);
 #define CRADLE_B3_CASE(TM_, TN_)                                                                                  \
   if (tm == TM_ && tn == TN_) {                                                                                   \
-    if (layout == 0) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, TM_, TN_>), grid, dim3(256), 0, s, p);    \
-    else if (layout == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, TM_, TN_>), grid, dim3(256), 0, s, p); \
-    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, TM_, TN_>), grid, dim3(256), 0, s, p);              \
+    if (layout == 0) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, TM_, TN_, SPLIT>), grid, dim3(256), 0, s, p);    \
+    else if (layout == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, TM_, TN_, SPLIT>), grid, dim3(256), 0, s, p); \
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, TM_, TN_, SPLIT>), grid, dim3(256), 0, s, p);              \
     return true;                                                                                                  \
   }
   CRADLE_B3_CASE(2, 2)
@@ -279,6 +286,11 @@ bool launch_gemm_bf16x3(int layout, const GemmParams& p, int tm, int tn, hipStre
   CRADLE_B3_CASE(1, 1)
 #undef CRADLE_B3_CASE
   return false;
+}
+
+// precision 1: split (three products); 2: plain bf16 (one)
+bool launch_gemm_bf16x3(int layout, const GemmParams& p, int tm, int tn, hipStream_t s) {
+  return p.precision == 2 ? launch_split<false>(layout, p, tm, tn, s) : launch_split<true>(layout, p, tm, tn, s);
 }
 
 }  // namespace cradle

@@ -458,7 +458,7 @@ int check_desc(const cradle_step_desc& d) {
   CRADLE_CHECK_ARG((uintptr_t)d.workspace % 256 == 0, "elbo_step: workspace must be 256-byte aligned");
   CRADLE_CHECK_ARG((uintptr_t)d.X % 16 == 0, "elbo_step: X must be 16-byte aligned");
   CRADLE_CHECK_ARG(d.temperature > 0.f, "elbo_step: temperature must be positive");
-  CRADLE_CHECK_ARG(d.precision == 0 || d.precision == 1, "elbo_step: precision must be 0 (fp32) or 1 (bf16x3), got %d",
+  CRADLE_CHECK_ARG(d.precision >= 0 && d.precision <= 2, "elbo_step: precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16), got %d",
                    d.precision);
   return CRADLE_OK;
 }

@@ -240,7 +240,7 @@ def _mat(t: torch.Tensor):
     return t.data_ptr(), t.stride(0)
 
 
-PRECISIONS = {"f32": 0, "bf16x3": 1}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
 _default_precision = "f32"
 
 

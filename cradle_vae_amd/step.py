@@ -270,7 +270,7 @@ class FusedElboStep:
         d.alpha = -1.0 if self.lm.alpha is None else float(self.lm.alpha)
         d.compute_grads = int(compute_grads)
         d.max_present = 0 if treatments_present is None else max(32, (int(treatments_present) + 31) & ~31)
-        d.precision = {"f32": 0, "bf16x3": 1}[getattr(self.lm, "precision", "f32")]
+        d.precision = {"f32": 0, "bf16x3": 1, "bf16": 2}[getattr(self.lm, "precision", "f32")]
         sample = self._calls % max(1, self.event_every) == 0
         if self.k1_events is not None and sample:
             ev = hip.EventPair()

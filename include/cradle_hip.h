@@ -140,8 +140,9 @@ typedef struct cradle_gemm_desc {
   int precision;   /* 0: fp32 MFMA (exact fp32, the reference's arithmetic: default).  1: "bf16x3" -- operands split
                       into bf16 hi + lo when a tile is staged, a_hi b_hi + a_hi b_lo + a_lo b_hi on
                       v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~1e-6..1e-5 relative per dot product), used for
-                      products of >= 1 GFLOP with 16-byte aligned operands, fp32 otherwise.  Optional mode, no
-                      counterpart in the reference (which computes in fp32). */
+                      products of >= 1 GFLOP with 16-byte aligned operands, fp32 otherwise.  2: "bf16" -- the same
+                      kernels with the one product of the rounded operands (plain bf16 inputs, fp32 accumulation, ~3
+                      digits per product).  Optional modes, no counterpart in the reference (which computes in fp32). */
   int k_valid;     /* 0: the operands hold K rows/columns along the inner dimension.  > 0 (and < K): they hold only
                       k_valid; K is that count rounded up by the caller so that the 16-byte loader applies (K % 4 == 0),
                       and the loader's range check supplies zeros from the end of an operand's last k_valid-long row on.
@@ -255,7 +256,7 @@ typedef struct cradle_step_desc {
                              [2] basal-encoder gradients (d_enc.*); the rest is final with the step.
                              NULL = off */
   uint64_t rng_seed_plated, rng_seed_local, rng_step;   /* used when the noise pointers are NULL */
-  int precision;          /* cradle_gemm_desc.precision for the step's GEMMs: 0 = fp32 (default), 1 = bf16x3 */
+  int precision;          /* cradle_gemm_desc.precision for the step's GEMMs: 0 = fp32 (default), 1 = bf16x3, 2 = bf16 */
   int max_present;        /* 0, or an upper bound on the number of DISTINCT treatments with a non-zero dosage in this
                              batch, when the caller knows one below N*kmax (a loader that has looked at the batch):
                              q(M), q(E|M) and the embedding encoder are evaluated on min(N*kmax, max_present, T) slots

@@ -26,12 +26,24 @@ pytestmark = pytest.mark.gpu
 def test_fused_step_matches_oracle_at_full_size(name, kmax, seed):
     from cradle_vae_amd import synthetic as syn
 
-    worst = compare_with_oracle(syn.SHAPES[name], kmax, seed, compact=(name == "replogle"))
+    worst = compare_with_oracle(syn.SHAPES[name], kmax, seed, compact=(name == "replogle"),
+                                precisions=("f32", "bf16x3", "bf16") if name == "norman" else ("f32", "bf16x3"))
     print(f"\n{name}: worst relative L2 gradient error / loss error per precision: {worst}")
     assert worst["bf16x3"] > worst["f32"]  # the mode was really taken
+    if name == "norman":
+        assert worst["bf16"] > worst["bf16x3"]
 
 
-def compare_with_oracle(shape, kmax, seed, compact, precisions=(("f32", 2e-5), ("bf16x3", 1e-2))):
+BARS = {  # per GEMM precision: relative L2 and max-scaled bars of every gradient tensor, relative bar of the loss terms
+    "f32": (2e-5, 2e-3, 1e-4),
+    "bf16x3": (1e-2, 2e-2, 1e-4),
+    # plain bf16 operands (optional mode, ~3 digits per product): the loss itself still meets 1e-4 (measured 5e-7: the
+    # rounding errors of 12.8 M logits average out), single loss terms are off by up to 6e-4, gradients by percents
+    "bf16": (1e-1, 2e-1, 2e-3),
+}
+
+
+def compare_with_oracle(shape, kmax, seed, compact, precisions=("f32", "bf16x3")):
     """One step of the fused path on a synthetic batch of `shape` against the fp64 oracle; the bars of the module
     docstring.  Returns the worst relative-L2 gradient error and the loss error per precision."""
     from cradle_vae_amd import synthetic as syn
@@ -69,25 +81,26 @@ def compare_with_oracle(shape, kmax, seed, compact, precisions=(("f32", 2e-5), (
     # 1.3e-4 .. 1.0e-3 per tensor, largest single entry 1e-2 of the tensor's maximum (encoder first layer,
     # q_mask_logits) -- against 2e-7 .. 4e-6 for fp32.  Bars for this mode: 2e-2 max-scaled, 1e-2 relative L2.
     worst = {}
-    for precision, l2_bar in precisions:
+    for precision in precisions:
+        l2_bar, max_bar, term_rtol = BARS[precision]
         lm = build_loss_module(case)
         lm.max_dosages_per_cell = kmax
         lm.precision = precision
         loss, metrics, grads = run_fused(lm, case)
         d = lm._fused.desc
         assert (d.N * d.kmax < d.T) == compact  # Replogle runs the compact treatment axis
-        assert d.precision == (1 if precision == "bf16x3" else 0)
+        assert d.precision == {"f32": 0, "bf16x3": 1, "bf16": 2}[precision]
 
         rtol = 1e-4
         assert abs(float(loss.detach()) - float(ref_loss)) <= rtol * abs(float(ref_loss)), (precision, float(loss), float(ref_loss))
         for k, v in ref_metrics.items():
-            assert abs(float(metrics[k]) - float(v)) <= rtol * max(1.0, abs(float(v))), (precision, k, float(metrics[k]), float(v))
+            assert abs(float(metrics[k]) - float(v)) <= term_rtol * max(1.0, abs(float(v))), (precision, k, float(metrics[k]), float(v))
         worst[precision] = 0.0
         for k, g in ref_grads.items():
             got = grads[k].detach().cpu().double()
             err = float((got - g).abs().max()) / max(float(g.abs().max()), 1e-12)
             l2 = float((got - g).norm()) / max(float(g.norm()), 1e-12)
-            assert err <= (2e-3 if precision == "f32" else 2e-2), (precision, k, err)
+            assert err <= max_bar, (precision, k, err)
             assert l2 <= l2_bar, (precision, k, l2)
             worst[precision] = max(worst[precision], l2)
         worst[precision + "_loss"] = abs(float(loss.detach()) - float(ref_loss)) / abs(float(ref_loss))

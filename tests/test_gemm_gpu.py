@@ -235,3 +235,24 @@ def test_padded_inner_dimension_with_k_valid(G, precision):
     close(ops.gemm(ops.NT, dl, Wx, k_valid=G, precision=precision), dl[:, :G].double() @ Wx.double().T, G)
     with pytest.raises(ops.hip.CradleHipError):
         ops.gemm(ops.NN, dl, Wh[: G - 1], k_valid=G)
+
+
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+def test_plain_bf16_mode_equals_a_product_of_rounded_operands(layout):
+    """precision="bf16": the split kernels without the two correction products -- the result is the fp32-accumulated
+    product of the operands rounded to bf16 (checked against exactly that in fp64), ~3e-3 relative to the exact one."""
+    from cradle_vae_amd import hip, ops
+
+    M, N, K = 1284, 400, 2560  # (an MN-major extent must be a multiple of 4 or have row slack for these kernels)
+    lay = getattr(ops, layout)
+    a = _rand(*((K, M) if layout == "TN" else (M, K)), seed=1)
+    b = _rand(*((N, K) if layout == "NT" else (K, N)), seed=2)
+    ws = torch.empty(hip.load().cradle_gemm_workspace_floats(lay, M, N, K, 0), device=DEV)
+    y = ops.gemm(lay, a, b, workspace=ws, precision="bf16")
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    A = ar.T if layout == "TN" else ar
+    B = br.T if layout == "NT" else br
+    _close(y, A @ B, K)  # fp32 accumulation of exact bf16 x bf16 products
+    exact = (a.double().T if layout == "TN" else a.double()) @ (b.double().T if layout == "NT" else b.double())
+    rel = float((y.double() - exact).norm() / exact.norm())
+    assert 1e-4 < rel < 1e-2, rel
