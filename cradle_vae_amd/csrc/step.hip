@@ -432,6 +432,7 @@ int check_desc(const cradle_step_desc& d) {
   CRADLE_CHECK_ARG(d.P > 0 && d.N > 0 && d.T > 0 && d.L > 0 && d.Q > 0 && d.G > 0 && d.He > 0 && d.Hm > 0 && d.Hd > 0,
                    "elbo_step: all sizes must be positive");
   CRADLE_CHECK_ARG(d.G >= 4, "elbo_step: n_phenos=%d below 4", d.G);
+  CRADLE_CHECK_ARG(d.G <= 16384, "elbo_step: n_genes=%d above 16384, the widest row K1 holds in registers", d.G);
   CRADLE_CHECK_ARG(d.kmax >= 1 && d.kmax <= 64, "elbo_step: kmax=%d out of range [1,64]", d.kmax);
   CRADLE_CHECK_ARG(d.max_present >= 0, "elbo_step: max_present=%d is negative", d.max_present);
   const cradle_mlp_ptrs* ms[4] = {&d.emb, &d.qce, &d.enc, &d.dec};

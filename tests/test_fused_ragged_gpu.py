@@ -57,3 +57,22 @@ def test_padding_genes_leave_no_trace():
     assert torch.equal(d[:, 301:], torch.zeros_like(d[:, 301:]))
     assert float(d[:, :301].abs().max()) > 0
     assert torch.equal(f.arena.grad[off + 301: off + 304], torch.full((3,), 7.0, device=DEV))
+
+
+def test_widest_supported_gene_axis_and_one_beyond():
+    """K1 holds a cell's genes in registers: 16384 is the widest row it takes (4 x 1024 threads x 4).  That width
+    matches the oracle; one vector more is refused with a message, by the step as by K1's own entry point."""
+    from cradle_vae_amd import hip
+    from cradle_vae_amd import synthetic as syn
+
+    shape = dataclasses.replace(syn.SHAPES["tiny"], name="tiny_g16384", n_cells=6, n_phenos=16384)
+    worst = compare_with_oracle(shape, 2, 9, compact=False, precisions=("f32",))
+    assert worst["f32_loss"] < 1e-5
+    import bench
+
+    lm, batch = bench.build(dataclasses.replace(shape, n_phenos=16388), DEV, seed=3)
+    with pytest.raises(hip.CradleHipError, match="n_genes"):
+        lm._fused_step().run(X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"],
+                             qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
+                             n_particles=shape.n_particles)
+    torch.cuda.synchronize()
