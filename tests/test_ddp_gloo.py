@@ -150,6 +150,24 @@ def _worker(rank, port, results):
         dist.all_gather(gathered, owned)
         a, b2 = set(gathered[0].tolist()), set(gathered[1].tolist())
         assert not (a & b2) and len(a | b2) == 2 * (n // WORLD)
+        # the sharded-update collectives (reduce-scatter -> update of this rank's piece -> all-gather of the pieces),
+        # in the forms the gloo backend gets: same sums and the same final buckets on every rank
+        from cradle_vae_amd import parallel as par
+
+        buckets = [torch.arange(8, dtype=torch.float32) * (rank + 1), torch.ones(4) * (rank + 2)]
+        for bk in buckets:
+            par.reduce_scatter_inplace_(bk, rank, WORLD)
+        half = buckets[0][rank * 4:(rank + 1) * 4]
+        assert torch.equal(half, torch.arange(8, dtype=torch.float32)[rank * 4:(rank + 1) * 4] * 3)  # (1 + 2) x
+        sums = par.all_gather_small(torch.tensor([float(rank), 10.0 + rank]), WORLD)
+        assert sums.tolist() == [0.0, 10.0, 1.0, 11.0]
+        for bk in buckets:  # "update": every rank rewrites its own piece only
+            n = bk.numel() // WORLD
+            bk[rank * n:(rank + 1) * n] += 100.0 * (rank + 1)
+            bk[(1 - rank) * n:(2 - rank) * n] = -1.0  # stale everywhere else
+        par.all_gather_inplace_many_(buckets, rank, WORLD)
+        assert buckets[0].tolist() == [100.0, 103.0, 106.0, 109.0, 212.0, 215.0, 218.0, 221.0]
+        assert buckets[1].tolist() == [105.0, 105.0, 205.0, 205.0]
         results[rank] = "ok"
     except BaseException as e:  # noqa: BLE001
         results[rank] = f"{type(e).__name__}: {e}"
