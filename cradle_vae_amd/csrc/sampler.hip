@@ -110,16 +110,20 @@ __device__ __forceinline__ float nb_log1p_inv_rate(float y) {
 __device__ __forceinline__ bool nb_inversion_ok(float c, float rate) {
   return rate >= kInvRateMin && c * nb_log1p_inv_rate(__frcp_rn(rate)) <= kInvMaxNegLogP0;
 }
-__device__ __forceinline__ float sample_nb_inversion(float c, float rate, float u) {
-  const float y = __frcp_rn(rate);  // 1/rate in (0, 4]
-  float pk = __expf(-c * nb_log1p_inv_rate(y));  // pmf(0) = (rate/(1+rate))^c >= exp(-15)
+// inv_tab[k] = 1 / (k + 1), k < 512, in LDS: the search's one reciprocal per step is a quarter-rate instruction
+// y = 1/rate in (0, 4], neg_log_p0 = c log1p(1/rate) <= 15: what nb_inversion_ok's test computed already
+__device__ __forceinline__ float sample_nb_inversion(float c, float y, float neg_log_p0, float u,
+                                                     const float* __restrict__ inv_tab) {
+  float pk = __expf(-neg_log_p0);  // pmf(0) = (rate/(1+rate))^c >= exp(-15)
   float cdf = pk, k = 0.f;
   if (u > cdf) {
     const float q = y * __frcp_rn(1.0f + y);  // 1/(1+rate)
     const float kmode = (c - 1.0f) * y;       // the pmf rises up to here: never stop the search before it
     // past the mode, stop once the increments no longer move the cdf: u is beyond what fp32 resolves
-    while (u > cdf && (k <= kmode || pk > 1e-9f) && k < 512.f) {
-      pk *= (k + c) * q * __frcp_rn(k + 1.0f);
+    int ki = 0;
+    while (u > cdf && (k <= kmode || pk > 1e-9f) && ki < 512) {
+      pk *= (k + c) * q * inv_tab[ki];
+      ++ki;
       k += 1.0f;
       cdf += pk;
     }
@@ -154,6 +158,8 @@ __global__ __launch_bounds__(NT) void nb_sample_accumulate_kernel(const float* _
   float* slot = dyn_lds;                                  // [G]
   int* queue = reinterpret_cast<int*>(dyn_lds + G);       // [G]
   __shared__ int queued;
+  __shared__ float inv_tab[512];
+  for (int i = threadIdx.x; i < 512; i += NT) inv_tab[i] = 1.0f / (float)(i + 1);  // (visible after the first softmax barrier)
   const int t = blockIdx.x, tid = threadIdx.x;
   const int G4 = G >> 2;
   const Philox ph{seed_lo, seed_hi};
@@ -204,14 +210,15 @@ __global__ __launch_bounds__(NT) void nb_sample_accumulate_kernel(const float* _
         const uint32_t ur[4] = {u4.x, u4.y, u4.z, u4.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float rate = fmaxf(cc[q] / (e[q] * mu_scale + kMuEps), kRateMin);
+          const float rate = fmaxf(cc[q] * fast_rcp(e[q] * mu_scale + kMuEps), kRateMin);
+          const float y = fast_rcp(rate), neg_log_p0 = cc[q] * nb_log1p_inv_rate(y);
           float x;
           if (TAIL && k * 4 + q >= Gv) {
             x = 0.f;  // behind the last gene
           } else if (sampler == SAMPLER_MEAN) {
-            x = cc[q] / rate;
-          } else if (nb_inversion_ok(cc[q], rate)) {
-            x = sample_nb_inversion(cc[q], rate, u01(ur[q]));
+            x = cc[q] * y;
+          } else if (rate >= kInvRateMin && neg_log_p0 <= kInvMaxNegLogP0) {  // == nb_inversion_ok(c, rate)
+            x = sample_nb_inversion(cc[q], y, neg_log_p0, u01(ur[q]), inv_tab);
           } else {
             slot[k * 4 + q] = rate;
             queue[atomicAdd(&queued, 1)] = k * 4 + q;
