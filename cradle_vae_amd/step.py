@@ -152,6 +152,7 @@ class FusedElboStep:
         # hip.EventPair whose two events fire when the decoder / basal-encoder gradients are final
         # (trainer.TrainStep starts their all-reduce while the rest of the backward pass runs)
         self.bucket_events = None
+        self.bucket_events_used = None  # indices of ev_bucket the caller waits for (None: all three)
         self._checked_states = set()
         # Random draws of the step.  Default: the HIP step draws its own noise (Philox4x32-10 in one launch,
         # csrc/elementwise.hip draw_noise_kernel) keyed by these seeds -- seed_plated identical on every
@@ -280,7 +281,8 @@ class FusedElboStep:
             d.ev_k1_begin, d.ev_k1_end = None, None
         be = self.bucket_events if compute_grads else None
         for i in range(3):  # bucket_events: two hip.EventPair = (out layer, decoder) and (basal encoder, unused)
-            d.ev_bucket[i] = None if be is None else (be[0].begin, be[0].end, be[1].begin)[i]
+            used = be is not None and (self.bucket_events_used is None or i in self.bucket_events_used)
+            d.ev_bucket[i] = (be[0].begin, be[0].end, be[1].begin)[i] if used else None
         if self.gemm_events is not None and sample:
             ev = hip.EventPair()
             self.gemm_events.append(ev)

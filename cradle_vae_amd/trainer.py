@@ -66,6 +66,7 @@ class TrainStep:
                 self._setup_regions(a, shardable)
             if self.overlap:
                 self.fused.bucket_events = (hip.EventPair(), hip.EventPair())
+                self.fused.bucket_events_used = {i for i in self.bucket_waits if i is not None}
                 self.comm_stream = torch.cuda.Stream(device=self.device)
 
     def _setup_regions(self, a, shardable):
@@ -76,6 +77,16 @@ class TrainStep:
 
         o_enc, o_dec, o_out = a.offsets["enc.W0"], a.offsets["dec.W0"], a.offsets["dec.Wh"]
         self.buckets = [(o_out, a.numel), (o_dec, o_out), (o_enc, o_dec), (0, o_enc)]
+        self.bucket_waits = [0, 1, 2, None]  # index into (ev[0].begin, ev[0].end, ev[1].begin); None: end of the step
+        # A collective costs the host 70-90 us to enqueue, whatever it moves (measured with a one-rank RCCL group,
+        # tools/bench_ddp_one_rank.py: c10d or librccl called directly, the same), and the host needs 0.55 ms for the
+        # step itself: with four buckets the N > 1 step is host-bound.  CRADLE_BUCKETS=2: the output layer (a third
+        # of the parameters, final 0.3 ms before the step ends) and everything else; 1: one bucket after the step.
+        nb = int(os.environ.get("CRADLE_BUCKETS", "2"))
+        if nb == 2:
+            self.buckets, self.bucket_waits = [(o_out, a.numel), (0, o_out)], [0, None]
+        elif nb == 1:
+            self.buckets, self.bucket_waits = [(0, a.numel)], [None]
         gw = self.group_world if shardable else 1
         self.piece_world = gw
         pieces = [[(s + r * ((e - s) // gw), (e - s) // gw) for (s, e) in self.buckets] for r in range(gw)]
@@ -154,7 +165,8 @@ class TrainStep:
             # encoder, the rest), each as soon as the event the step recorded for it has fired
             lib = hip.load()
             ev = self.fused.bucket_events
-            waits = (ev[0].begin, ev[0].end, ev[1].begin, None)
+            evs = (ev[0].begin, ev[0].end, ev[1].begin)
+            waits = [None if i is None else evs[i] for i in self.bucket_waits]
             cur = torch.cuda.current_stream()
             with torch.cuda.stream(self.comm_stream):
                 cs = self.comm_stream.cuda_stream

@@ -20,9 +20,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, port, overlap, out, sync="allreduce"):
+def _worker(rank, port, overlap, out, sync="allreduce", buckets="2"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo",
-                      CRADLE_OVERLAP_ALLREDUCE="1" if overlap else "0", CRADLE_GRAD_SYNC=sync)
+                      CRADLE_OVERLAP_ALLREDUCE="1" if overlap else "0", CRADLE_GRAD_SYNC=sync, CRADLE_BUCKETS=buckets)
     import torch.distributed as dist
 
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
@@ -46,12 +46,12 @@ def _worker(rank, port, overlap, out, sync="allreduce"):
         dist.destroy_process_group()
 
 
-def _run(overlap, sync="allreduce"):
+def _run(overlap, sync="allreduce", buckets="2"):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         out = mgr.dict()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, port, overlap, out, sync)) for r in range(WORLD)]
+        procs = [ctx.Process(target=_worker, args=(r, port, overlap, out, sync, buckets)) for r in range(WORLD)]
         for p in procs:
             p.start()
         for p in procs:
@@ -75,6 +75,11 @@ def test_overlapped_bucket_allreduce_equals_single_allreduce():
     assert torch.equal(c[0][0], c[1][0]), "ranks diverged with reduce-scatter / sharded Adam / all-gather"
     assert torch.equal(c[0][0], a[0][0]), "sharded and full optimiser updates disagree"
     assert c[0][1] == a[0][1]
+    # four buckets (finer overlap, more collectives) instead of the default two: another partition of the clip norm's
+    # sum, so equal up to its rounding, and again the same on both ranks
+    d = _run(overlap=True, sync="rs_ag", buckets="4")
+    assert torch.equal(d[0][0], d[1][0])
+    assert torch.allclose(d[0][0], c[0][0], rtol=1e-5, atol=1e-7)
 
 
 def _rccl_worker(port, overlap, out, sync="allreduce"):

@@ -1,0 +1,42 @@
+"""The data-parallel step's stream / event / collective structure on the one GPU a box has: backend nccl (RCCL) with
+a one-rank group, TrainStep told world_size = 2 (bucket events, communication stream, reduce-scatter, sharded Adam,
+all-gather -- the collectives move nothing, their launches and orderings are real).  Times the step under the
+CRADLE_* settings given on the command line: python tools/bench_ddp_one_rank.py [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29531")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+import bench
+from cradle_vae_amd import synthetic as syn
+from cradle_vae_amd.trainer import TrainStep
+
+shape = syn.SHAPES[os.environ.get("SHAPE", "norman")]
+lm, batch = bench.build(shape, "cuda:0", seed=1000)
+st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=2)
+for _ in range(20):
+    st(batch, n_particles=shape.n_particles)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    st(batch, n_particles=shape.n_particles)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+torch.cuda.synchronize()
+host = []
+for _ in range(10):
+    t1 = time.perf_counter()
+    for _ in range(8):
+        st(batch, n_particles=shape.n_particles)
+    host.append((time.perf_counter() - t1) / 8 * 1e3)
+    torch.cuda.synchronize()
+host.sort()
+print(f"host enqueue {host[len(host)//2]:.3f} ms/step (bursts of 8 after a sync)")
+print(f"{shape.name} sync={st.grad_sync} overlap={st.overlap} async_allgather={getattr(st, 'async_allgather', None)}: "
+      f"{dt*1e3:.4f} ms/step = {shape.n_cells/dt:.0f} cells/s per rank", flush=True)
+dist.destroy_process_group()
