@@ -47,7 +47,7 @@ class TrainStep:
             self.exp_avg = torch.zeros_like(a.flat)
             self.exp_avg_sq = torch.zeros_like(a.flat)
             self.norm_ws = torch.zeros(hip.load().cradle_adam_workspace_floats(), device=self.device)
-            # N > 1: gradients are synchronised in four buckets, in the order the backward pass finishes them, on a
+            # N > 1: gradients are synchronised in buckets (CRADLE_BUCKETS, two by default), in the order the backward pass finishes them, on a
             # communication stream that runs under the remaining backward kernels.  Two forms (CRADLE_GRAD_SYNC):
             #   "rs_ag" (default): reduce-scatter every bucket, clip + Adam on this rank's 1/N of each bucket only,
             #           all-gather the updated parameters -- the same bytes on the wire as an all-reduce, 1/N of the
@@ -64,6 +64,13 @@ class TrainStep:
                 self.grad_sync = "allreduce"
             if world_size > 1:
                 self._setup_regions(a, shardable)
+                if os.environ.get("GPU_MAX_HW_QUEUES", "4") not in ("5", "6", "7"):
+                    import warnings
+
+                    warnings.warn("multi-GPU step with GPU_MAX_HW_QUEUES=%s: the step's streams share hardware queues "
+                                  "with the communicator's below 5 and the overlapped collectives stall from 8 on; "
+                                  "export GPU_MAX_HW_QUEUES=6 before the process starts (bench.py and train.py do)"
+                                  % os.environ.get("GPU_MAX_HW_QUEUES", "4 (the runtime's default)"))
             if self.overlap:
                 self.fused.bucket_events = (hip.EventPair(), hip.EventPair())
                 self.fused.bucket_events_used = {i for i in self.bucket_waits if i is not None}
@@ -78,10 +85,11 @@ class TrainStep:
         o_enc, o_dec, o_out = a.offsets["enc.W0"], a.offsets["dec.W0"], a.offsets["dec.Wh"]
         self.buckets = [(o_out, a.numel), (o_dec, o_out), (o_enc, o_dec), (0, o_enc)]
         self.bucket_waits = [0, 1, 2, None]  # index into (ev[0].begin, ev[0].end, ev[1].begin); None: end of the step
-        # A collective costs the host 70-90 us to enqueue, whatever it moves (measured with a one-rank RCCL group,
-        # tools/bench_ddp_one_rank.py: c10d or librccl called directly, the same), and the host needs 0.55 ms for the
-        # step itself: with four buckets the N > 1 step is host-bound.  CRADLE_BUCKETS=2: the output layer (a third
-        # of the parameters, final 0.3 ms before the step ends) and everything else; 1: one bucket after the step.
+        # Fewer, larger buckets: every collective is four to six launches and event hops (c10d's own stream and
+        # events around the RCCL kernel), about 10 us each of host and stream time (tools/micro/c10d_cost.py), and the
+        # host needs 0.55 ms for the step itself.  CRADLE_BUCKETS=2: the output layer (a third of the parameters,
+        # final 0.3 ms before the step ends) and everything else; 4: one per layer group; 1: one bucket after the step.
+        # What costs far more than the bucket count is the number of hardware queues (bench.py sets it for N > 1).
         nb = int(os.environ.get("CRADLE_BUCKETS", "2"))
         if nb == 2:
             self.buckets, self.bucket_waits = [(o_out, a.numel), (0, o_out)], [0, None]

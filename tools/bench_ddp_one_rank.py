@@ -1,8 +1,11 @@
 """The data-parallel step's stream / event / collective structure on the one GPU a box has: backend nccl (RCCL) with
 a one-rank group, TrainStep told world_size = 2 (bucket events, communication stream, reduce-scatter, sharded Adam,
-all-gather -- the collectives move nothing, their launches and orderings are real).  Times the step under the
+all-gather -- the collectives move nothing, their launches and orderings are real).  TOLD_WORLD=1: the group is alive
+and the step takes the single-GPU path (what a communicator costs by existing).  Times the step under the
 CRADLE_* settings given on the command line: python tools/bench_ddp_one_rank.py [steps]"""
 import os, sys, time
+if "CRADLE_HW_QUEUES" in os.environ:  # what bench.py does for N > 1 (default there: 6); unset here = the runtime's 4
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["CRADLE_HW_QUEUES"]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
@@ -18,7 +21,7 @@ from cradle_vae_amd.trainer import TrainStep
 
 shape = syn.SHAPES[os.environ.get("SHAPE", "norman")]
 lm, batch = bench.build(shape, "cuda:0", seed=1000)
-st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=2)
+st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=int(os.environ.get("TOLD_WORLD", "2")))
 for _ in range(20):
     st(batch, n_particles=shape.n_particles)
 torch.cuda.synchronize()
