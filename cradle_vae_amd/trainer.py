@@ -176,18 +176,21 @@ class TrainStep:
             evs = (ev[0].begin, ev[0].end, ev[1].begin)
             waits = [None if i is None else evs[i] for i in self.bucket_waits]
             cur = torch.cuda.current_stream()
-            with torch.cuda.stream(self.comm_stream):
-                cs = self.comm_stream.cuda_stream
-                for (s, e), w in zip(self.buckets, waits):
-                    if w is not None:
-                        hip.check(lib.cradle_stream_wait_event(cs, w), "stream_wait_event")
-                    else:
-                        self.comm_stream.wait_stream(cur)  # q(M), q(E|M), q(qc_E): final when the step is
-                    if shard:
-                        parallel.reduce_scatter_inplace_(a.grad[s:e], rk, gw)
-                    else:
-                        parallel._all_reduce(a.grad[s:e])
-            cur.wait_stream(self.comm_stream)
+            sync = (lambda g: parallel.reduce_scatter_inplace_(g, rk, gw)) if shard else parallel._all_reduce
+            early = [(b, w) for b, w in zip(self.buckets, waits) if w is not None]
+            if early:
+                with torch.cuda.stream(self.comm_stream):
+                    for (s, e), w in early:
+                        hip.check(lib.cradle_stream_wait_event(self.comm_stream.cuda_stream, w), "stream_wait_event")
+                        sync(a.grad[s:e])
+            # the bucket that is final only when the step is (q(M), q(E|M), q(qc_E)) has nothing to run under: it goes
+            # on the step's own stream, two stream hand-overs fewer than through the communication stream (the process
+            # group runs its collectives in issue order whatever stream they come from)
+            for (s, e), w in zip(self.buckets, waits):
+                if w is None:
+                    sync(a.grad[s:e])
+            if early:
+                cur.wait_stream(self.comm_stream)
         # |g|^2 = in-order sum of the region sums (bucket x rank), whoever computes them
         if shard:
             mine = self.region_sums[:self._my_regions[2]]
