@@ -24,12 +24,12 @@ import sys
 import time
 
 # N > 1: HIP's default of 4 hardware queues per process is too few once a RCCL communicator exists next to the step's
-# three streams and the communication stream (streams that share a queue run one after the other: the step took
-# 1.17 ms instead of 0.95 ms with a process group merely alive, profiles/r02_ddp_one_rank_emulation.txt).  6 keeps the
-# step's streams apart; 8 or more made the overlapped collectives twice as slow on this runtime.  The runtime reads the
-# variable when it starts, so it is set before torch is imported.
+# streams: streams that share a queue run one after the other, and which ones share depends on the order they were
+# created in (1.17 ms instead of 0.95 ms per step with a process group merely alive; 0.95 ... 1.3 ms at 4-7 queues
+# depending on which stream the step runs on: profiles/r02_ddp_one_rank_emulation.txt).  16 gives every stream a queue
+# of its own.  The runtime reads the variable when it starts, so it is set before torch is imported.
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("CRADLE_HW_QUEUES", "6")
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("CRADLE_HW_QUEUES", "16")
 
 import torch
 

@@ -47,8 +47,9 @@ class TrainStep:
             self.exp_avg = torch.zeros_like(a.flat)
             self.exp_avg_sq = torch.zeros_like(a.flat)
             self.norm_ws = torch.zeros(hip.load().cradle_adam_workspace_floats(), device=self.device)
-            # N > 1: gradients are synchronised in buckets (CRADLE_BUCKETS, two by default), in the order the backward pass finishes them, on a
-            # communication stream that runs under the remaining backward kernels.  Two forms (CRADLE_GRAD_SYNC):
+            # N > 1: gradients are synchronised in buckets (CRADLE_BUCKETS: one by default, after the step; with 2 or
+            # 4, in the order the backward pass finishes them, on a communication stream that runs under the remaining
+            # backward kernels).  Two forms (CRADLE_GRAD_SYNC):
             #   "rs_ag" (default): reduce-scatter every bucket, clip + Adam on this rank's 1/N of each bucket only,
             #           all-gather the updated parameters -- the same bytes on the wire as an all-reduce, 1/N of the
             #           optimiser's HBM traffic, and collectives RCCL can run as direct exchanges over the xGMI mesh;
@@ -64,12 +65,12 @@ class TrainStep:
                 self.grad_sync = "allreduce"
             if world_size > 1:
                 self._setup_regions(a, shardable)
-                if os.environ.get("GPU_MAX_HW_QUEUES", "4") not in ("5", "6", "7"):
+                if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
                     import warnings
 
                     warnings.warn("multi-GPU step with GPU_MAX_HW_QUEUES=%s: the step's streams share hardware queues "
-                                  "with the communicator's below 5 and the overlapped collectives stall from 8 on; "
-                                  "export GPU_MAX_HW_QUEUES=6 before the process starts (bench.py and train.py do)"
+                                  "with the communicator's and run one after the other (0.2-0.3 ms per step); export "
+                                  "GPU_MAX_HW_QUEUES=16 before the process starts (bench.py and train.py do)"
                                   % os.environ.get("GPU_MAX_HW_QUEUES", "4 (the runtime's default)"))
             if self.overlap:
                 self.fused.bucket_events = (hip.EventPair(), hip.EventPair())
@@ -85,12 +86,14 @@ class TrainStep:
         o_enc, o_dec, o_out = a.offsets["enc.W0"], a.offsets["dec.W0"], a.offsets["dec.Wh"]
         self.buckets = [(o_out, a.numel), (o_dec, o_out), (o_enc, o_dec), (0, o_enc)]
         self.bucket_waits = [0, 1, 2, None]  # index into (ev[0].begin, ev[0].end, ev[1].begin); None: end of the step
-        # Fewer, larger buckets: every collective is four to six launches and event hops (c10d's own stream and
-        # events around the RCCL kernel), about 10 us each of host and stream time (tools/micro/c10d_cost.py), and the
-        # host needs 0.55 ms for the step itself.  CRADLE_BUCKETS=2: the output layer (a third of the parameters,
-        # final 0.3 ms before the step ends) and everything else; 4: one per layer group; 1: one bucket after the step.
-        # What costs far more than the bucket count is the number of hardware queues (bench.py sets it for N > 1).
-        nb = int(os.environ.get("CRADLE_BUCKETS", "2"))
+        # Default ONE bucket: all of it after the step, on the step's own stream.  CRADLE_BUCKETS=2 reduces the output
+        # layer (a third of the parameters, final 0.3 ms before the step ends) under the rest of the backward pass on
+        # the communication stream, 4 cuts per layer group.  On this runtime the communication stream's wait for the
+        # step's mid-backward event stalls the step (2.1 instead of 1.0 ms) whenever that stream has a hardware queue
+        # to itself, and runs well (1.02 ms) only under some sharings of queues (GPU_MAX_HW_QUEUES=6 with the step on
+        # the null stream): measured with a one-rank RCCL group, tools/bench_ddp_one_rank.py, DESIGN 6.  One bucket
+        # never touches that stream: 0.98 ms at 6 ... 32 queues.
+        nb = int(os.environ.get("CRADLE_BUCKETS", "1"))
         if nb == 2:
             self.buckets, self.bucket_waits = [(o_out, a.numel), (0, o_out)], [0, None]
         elif nb == 1:

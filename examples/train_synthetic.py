@@ -11,8 +11,8 @@ import json
 import os
 import sys
 
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # six hardware queues per process for N > 1 (see bench.py)
-    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("CRADLE_HW_QUEUES", "6")
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # sixteen hardware queues per process for N > 1 (see bench.py)
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("CRADLE_HW_QUEUES", "16")
 
 import torch
 

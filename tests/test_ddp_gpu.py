@@ -75,11 +75,13 @@ def test_overlapped_bucket_allreduce_equals_single_allreduce():
     assert torch.equal(c[0][0], c[1][0]), "ranks diverged with reduce-scatter / sharded Adam / all-gather"
     assert torch.equal(c[0][0], a[0][0]), "sharded and full optimiser updates disagree"
     assert c[0][1] == a[0][1]
-    # four buckets (finer overlap, more collectives) instead of the default two: another partition of the clip norm's
-    # sum, so equal up to its rounding, and again the same on both ranks
-    d = _run(overlap=True, sync="rs_ag", buckets="4")
-    assert torch.equal(d[0][0], d[1][0])
-    assert torch.allclose(d[0][0], c[0][0], rtol=1e-5, atol=1e-7)
+    # four buckets (finer overlap, more collectives), and the default of one (everything after the step, on the
+    # step's own stream): other partitions of the clip norm's sum, so equal up to its rounding, and again the same
+    # on both ranks
+    for nb in ("4", "1"):
+        d = _run(overlap=True, sync="rs_ag", buckets=nb)
+        assert torch.equal(d[0][0], d[1][0]), nb
+        assert torch.allclose(d[0][0], c[0][0], rtol=1e-5, atol=1e-7), nb
 
 
 def _rccl_worker(port, overlap, out, sync="allreduce"):
@@ -87,7 +89,7 @@ def _rccl_worker(port, overlap, out, sync="allreduce"):
     on the only GPU a test box has.  world_size 2 is what TrainStep is told, so the bucket events, the
     communication stream and RCCL's own stream ordering are all exercised; the group itself has one rank."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CRADLE_OVERLAP_ALLREDUCE="1" if overlap else "0",
-                      CRADLE_GRAD_SYNC=sync)
+                      CRADLE_GRAD_SYNC=sync, CRADLE_BUCKETS="2")  # two buckets: the communication stream is in use
     import torch.distributed as dist
 
     torch.cuda.set_device(0)

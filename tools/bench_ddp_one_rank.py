@@ -4,7 +4,7 @@ all-gather -- the collectives move nothing, their launches and orderings are rea
 and the step takes the single-GPU path (what a communicator costs by existing).  Times the step under the
 CRADLE_* settings given on the command line: python tools/bench_ddp_one_rank.py [steps]"""
 import os, sys, time
-if "CRADLE_HW_QUEUES" in os.environ:  # what bench.py does for N > 1 (default there: 6); unset here = the runtime's 4
+if "CRADLE_HW_QUEUES" in os.environ:  # what bench.py does for N > 1 (default there: 16); unset here = the runtime's 4
     os.environ["GPU_MAX_HW_QUEUES"] = os.environ["CRADLE_HW_QUEUES"]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,6 +22,10 @@ from cradle_vae_amd.trainer import TrainStep
 shape = syn.SHAPES[os.environ.get("SHAPE", "norman")]
 lm, batch = bench.build(shape, "cuda:0", seed=1000)
 st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=int(os.environ.get("TOLD_WORLD", "2")))
+if os.environ.get("MAIN_STREAM") == "pool":  # the step on a stream of torch's pool instead of the device's null stream
+    main = torch.cuda.Stream()
+    main.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(main)
 for _ in range(20):
     st(batch, n_particles=shape.n_particles)
 torch.cuda.synchronize()

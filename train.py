@@ -26,9 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# N > 1: six hardware queues per process instead of HIP's four, set before the runtime starts (see bench.py)
+# N > 1: sixteen hardware queues per process instead of HIP's four, set before the runtime starts (see bench.py)
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("CRADLE_HW_QUEUES", "6")
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("CRADLE_HW_QUEUES", "16")
 
 RESULTS_BASE_DIR = "results/"
 
