@@ -124,8 +124,11 @@ def gemm_flops_fwd(s, slots=None):
 
 def loss_parity(lm, shape, batch, device):
     """One forward of the fused HIP step on the bench's own batch and its trained parameters against the
-    fp64 CPU oracle on the same injected noise -> relative error of the loss and the largest relative error
-    over the loss terms (the parity bar is 1e-4, tests/test_fused_fullsize_gpu.py)."""
+    fp64 CPU oracle on the same injected noise -> relative error of the loss, the relative error of every loss
+    term (|got - ref| / max(1, |ref|); the parity bar is 1e-4, tests/test_fused_fullsize_gpu.py) and the number of
+    straight-through mask bits that differ from the oracle's (a relaxed-Bernoulli logit within fp32 rounding of zero
+    rounds to the other side than in fp64: a different -- equally valid -- discrete sample, not an arithmetic
+    error; terms are only comparable when there are none)."""
     from cradle_vae_amd import synthetic as syn
     from oracle import cradle_oracle as co
 
@@ -141,12 +144,18 @@ def loss_parity(lm, shape, batch, device):
     f64 = lambda d: {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in d.items()}
     params, b = f64(lm.state_dict()), f64({k: v for k, v in batch.items() if k != "idx" and torch.is_tensor(v)})
     with torch.no_grad():
-        ref, ref_metrics, _ = co.elbo_loss(
+        ref, ref_metrics, inter = co.elbo_loss(
             params, X=b["X"], D=b["D"], qc=b["qc"], cfX=b["cfX"], library_size=b["library_size"],
             D_obs_counts=b["D_obs_counts"], qc_obs_counts=b["qc_obs_counts"], noise=f64(n1), cf_noise=f64(n2),
             n_particles=shape.n_particles, beta=shape.beta)
-    terms = max(abs(float(metrics[k]) - float(v)) / max(1.0, abs(float(v))) for k, v in ref_metrics.items())
-    return abs(float(loss) - float(ref)) / abs(float(ref)), terms
+    terms = {k: abs(float(metrics[k]) - float(v)) / max(1.0, abs(float(v))) for k, v in ref_metrics.items()}
+    flips = None
+    fs = getattr(lm, "_fused", None)
+    if fs is not None and fs.desc.N * fs.desc.kmax >= fs.desc.T and not fs.desc.max_present:  # full treatment axis
+        P, T, L = shape.n_particles, shape.n_treatments, shape.n_latent
+        mask = fs.intermediate("mask").view(2 * P, T, L).cpu().double()
+        flips = int((mask[:P] != inter["mask"]).sum()) + int((mask[P:] != inter["cf_mask"]).sum())
+    return abs(float(loss) - float(ref)) / abs(float(ref)), terms, flips
 
 
 def cpu_baseline(shape, seconds_budget=25.0, as_written=False):
@@ -203,6 +212,106 @@ def cpu_baseline(shape, seconds_budget=25.0, as_written=False):
     }
 
 
+ATE_N_ALT, ATE_PARTICLES, ATE_CHUNK = 236, 2500, 128  # Norman's perturbations; eval.py:330-331 (n_particles, batch_size)
+
+
+def ate_workload(shape):
+    """dosages of the ATE leg: ATE_N_ALT two-guide perturbations against the empty control (eval.py:90-97)."""
+    T = shape.n_treatments
+    g = torch.Generator().manual_seed(0)
+    D_alt = torch.zeros(ATE_N_ALT, T)
+    D_alt[torch.arange(ATE_N_ALT), torch.randint(0, T, (ATE_N_ALT,), generator=g)] = 1.0
+    D_alt[torch.arange(ATE_N_ALT), torch.randint(0, T, (ATE_N_ALT,), generator=g)] = 1.0
+    return D_alt, torch.zeros(1, T)
+
+
+def ate_cpu_baseline(lm, shape, n_alt=40):
+    """The reference's ATE loop (oracle.model_average_treatment_effect: one model call per perturbation and particle
+    chunk, both decoder variants, x_good and x_bad drawn; pinned draw for draw to the reference by
+    tests/golden/ate_sampled_tiny.npz) on this host's cores, on a bounded sample of the same workload."""
+    from oracle import cradle_oracle as co
+
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "64")))))
+    params = {k: v.detach().cpu().float() for k, v in lm.state_dict().items()}
+    D_alt, D_ctl = ate_workload(shape)
+    t0 = time.perf_counter()
+    _, calls = co.model_average_treatment_effect(
+        params, dosages_alt=D_alt, dosages_control=D_ctl, quality=torch.ones(1, shape.n_qc),
+        library_size=1e4 * torch.ones(1), n_particles=ATE_CHUNK, method="perturbseq", batch_size=ATE_CHUNK,
+        max_alt=n_alt, max_chunks=1)
+    dt = time.perf_counter() - t0
+    return {"value": calls * ATE_CHUNK / dt, "unit": "(perturbation, particle) rows/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"one particle chunk of {ATE_CHUNK}: the guide call, the control and {n_alt} of the {ATE_N_ALT} "
+                      f"perturbations ({calls} model calls of {ATE_CHUNK} rows, as the reference writes them: both decoder "
+                      f"variants, x_good and x_bad drawn), {dt:.1f} s"}
+
+
+def ate_bench(lm, shape, device, args):
+    """The predictor half of north_star: model-side average treatment effects at Norman's evaluation size
+    (eval.py:90-97,330-331 -> analysis/average_treatment_effects.py:78-203): ATE_N_ALT perturbations x ATE_PARTICLES
+    particles in chunks of ATE_CHUNK, method perturbseq, counts drawn.  Whole call timed (median of 3); one more call with
+    HIP events around every GEMM and sampler launch gives the kernel-level figures."""
+    from cradle_vae_amd import ops
+    from cradle_vae_amd.predictor import cradle_vae_Predictor
+
+    pred = cradle_vae_Predictor(lm.model, lm.guide)
+    D_alt, D_ctl = ate_workload(shape)
+    kw = dict(dosages_alt=D_alt, dosages_control=D_ctl, quality=torch.ones(1, shape.n_qc), method="perturbseq",
+              condition_values=dict(library_size=1e4 * torch.ones(1)), batch_size=ATE_CHUNK)
+    pred.estimate_average_treatment_effects(n_particles=ATE_CHUNK, **kw)  # warm-up: one chunk
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = pred.estimate_average_treatment_effects(n_particles=ATE_PARTICLES, **kw)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[1]
+    ops.KERNEL_TIMERS.clear()
+    ops.KERNEL_TIMING = "all"
+    pred.estimate_average_treatment_effects(n_particles=ATE_PARTICLES, **kw)
+    torch.cuda.synchronize()
+    ops.KERNEL_TIMING = False
+    k9 = [t[1].elapsed_time(t[2]) * 1e-3 for t in ops.KERNEL_TIMERS if t[0] == "nb_sample_accumulate"]
+    G, L, Hd = shape.n_phenos, shape.n_latent, shape.decoder_n_hidden
+    dec = [(t[0], t[1].elapsed_time(t[2]) * 1e-3) for t in ops.KERNEL_TIMERS if isinstance(t[0], tuple) and t[0][2] >= G]
+    ops.KERNEL_TIMERS.clear()
+    rows = ATE_PARTICLES * (ATE_N_ALT + 1)
+    res = {"workload": f"{shape.name}: {ATE_N_ALT} perturbations + control x {ATE_PARTICLES} particles (chunks of {ATE_CHUNK}), "
+                       f"G={G}, method perturbseq, Gamma-Poisson counts drawn (eval.py:90-97,330-331)",
+           "ms": dt * 1e3, "value": rows / dt, "unit": "(perturbation, particle) rows/s", "runs_ms": [t * 1e3 for t in times],
+           "finite": bool(torch.isfinite(torch.from_numpy(out.X)).all())}
+    if k9:
+        # K9 per launch: reads 4*G B of logits per (particle, perturbation) row, writes 4*G B per perturbation
+        conds = ATE_N_ALT + 1
+        slab = max(1, min(1 << 16, (1 << 27) // G) // ATE_CHUNK)
+        slab = -(-conds // -(-conds // slab))  # ate.py: equal slabs of perturbations per decoder pass
+        alg = 4.0 * G * (ATE_CHUNK * slab + slab)
+        full = [t for t in k9 if t >= 0.5 * max(k9)]  # (the last chunk of 2500 = 19 x 128 + 68 is shorter)
+        t_k9 = sum(full) / len(full)
+        res["roofline"] = {"bound": "hbm", "achieved": alg / t_k9 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": alg / t_k9 / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "nb_sample_accumulate_kernel + partial_sums_kernel (K9: softmax, Gamma-Poisson draw, "
+                                     "perturb-seq transform, particle sum)",
+                           "launch_us": t_k9 * 1e6, "launches_timed": len(full), "algorithmic_bytes_per_launch": alg,
+                           "rows_per_launch": ATE_CHUNK * slab, "total_ms": sum(k9) * 1e3,
+                           "note": "HBM is the nominal bound; the kernel is bound by its random-number and "
+                                   "transcendental ALU work (DESIGN 4, K9)"}
+    if dec:
+        fl = sum(2.0 * k[1] * k[2] * k[3] for k, _ in dec)
+        tt = sum(t for _, t in dec)
+        res["mfma"] = {"kernel": "gemm_f32_kernel NT (decoder output layer of every particle chunk x perturbation slab)",
+                       "flops": fl, "total_ms": tt * 1e3, "achieved": fl / tt / 1e12, "peak": MFMA_F32_PEAK_TF,
+                       "unit": "TFLOP/s", "frac": fl / tt / 1e12 / MFMA_F32_PEAK_TF, "launches_timed": len(dec),
+                       "decoder_flops_per_row": 2.0 * (3 * L * Hd + Hd * Hd * max(shape.decoder_n_layers, 1) + Hd * G),
+                       "whole_call_frac": 2.0 * (3 * L * Hd + Hd * Hd * max(shape.decoder_n_layers, 1) + Hd * G) * rows
+                                          / dt / 1e12 / MFMA_F32_PEAK_TF}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = ate_cpu_baseline(lm, shape)
+    return res
+
+
 def secondary_shape(name, device, args, precision="f32"):
     """The same step at another shape (north_star quotes the Replogle-like one too) or in the optional split-bf16
     GEMM mode, measured after the main region on the same device: side information, not the headline metric."""
@@ -230,7 +339,9 @@ def secondary_shape(name, device, args, precision="f32"):
         res["dtype"] = ("bf16x3 (bf16 hi+lo operands, 3 products, fp32 accumulate)" if precision == "bf16x3" else
                         "bf16 (operands rounded to bf16, fp32 accumulate)") + " in the GEMMs of >= 1 GFLOP; f32 elsewhere"
         if not args.no_cpu_baseline:
-            res["loss_rel_err_vs_oracle"], res["loss_terms_max_rel_err_vs_oracle"] = loss_parity(lm, shape, batch, device)
+            rel, terms, flips = loss_parity(lm, shape, batch, device)
+            res["loss_rel_err_vs_oracle"], res["loss_terms_max_rel_err_vs_oracle"] = rel, max(terms.values())
+            res["mask_bits_differing_from_oracle"] = flips
     return res
 
 
@@ -248,6 +359,7 @@ def main():
     ap.add_argument("--step-impl", default="auto", choices=["auto", "fused", "modular"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Replogle-shaped side measurement (N=1 only)")
+    ap.add_argument("--no-ate", action="store_true", help="skip the ATE (predictor) leg (N=1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
@@ -385,6 +497,8 @@ def main():
             "roofline": roofline,
             "mfma": mfma,
         }
+        if world == 1 and not args.no_ate and shape.n_treatments <= 4096:
+            out["ate"] = ate_bench(lm, shape, device, args)
         if world == 1 and args.shape == "norman" and not args.no_secondary:
             out["replogle_shape"] = secondary_shape("replogle", device, args)
             # optional arithmetic mode, a side number: the headline above is fp32 (the reference's precision)
@@ -397,9 +511,11 @@ def main():
                                    "sample": f"not run: the reference's dense form at T={shape.n_treatments} treatments"}
         elif not args.no_cpu_baseline and world == 1:
             if stepper.fused is not None:
-                rel, rel_terms = loss_parity(lm, shape, batch, device)
+                rel, terms, flips = loss_parity(lm, shape, batch, device)
                 out["loss_rel_err_vs_oracle"] = rel
-                out["loss_terms_max_rel_err_vs_oracle"] = rel_terms
+                out["loss_terms_max_rel_err_vs_oracle"] = max(terms.values())
+                out["loss_terms_rel_err_vs_oracle"] = terms
+                out["mask_bits_differing_from_oracle"] = flips
             out["cpu_baseline"] = cpu_baseline(shape, seconds_budget=15.0)
             aw = cpu_baseline(shape, seconds_budget=12.0, as_written=True)
             out["cpu_baseline"]["as_written"] = {k: aw[k] for k in ("value", "unit", "sample")}

@@ -99,11 +99,18 @@ __global__ __launch_bounds__(256) void adam_regions_kernel(float* __restrict__ p
                                                            float eps, float wd, float bc1, float sqrt_bc2, float max_norm,
                                                            float grad_scale, const float* __restrict__ all_sums, int n_sums,
                                                            float* __restrict__ norm_out, const int* __restrict__ skip_flags) {
-  if (skip_flags && *skip_flags != 0) return;
   float tot = 0.f;
   for (int k = 0; k < n_sums; ++k) tot += all_sums[k];  // fixed order, the same on every rank
   const float norm = sqrtf(tot) * fabsf(grad_scale);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && norm_out) *norm_out = norm;
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  // A rank whose step rejected its input puts a NaN into its gradients before they are summed
+  // (cradle_grad_poison_if_flagged): the sum of squares every rank sees is then not finite and ALL ranks skip the
+  // update together -- the decision is global although the flags word is local.  norm_out[1] counts skipped updates.
+  if ((skip_flags && *skip_flags != 0) || !(fabsf(tot) <= 3.0e38f)) {
+    if (first && norm_out) { norm_out[0] = norm; norm_out[1] += 1.0f; }
+    return;
+  }
+  if (first && norm_out) norm_out[0] = norm;
   float scale = grad_scale;
   if (max_norm > 0.f) scale *= fminf(1.0f, max_norm / (norm + 1e-6f));
   const float step_size = lr / bc1;
@@ -118,6 +125,10 @@ __global__ __launch_bounds__(256) void adam_regions_kernel(float* __restrict__ p
     v[i] = vi;
     p[i] = pi - step_size * mi / (sqrtf(vi) / sqrt_bc2 + eps);
   }
+}
+
+__global__ void poison_if_flagged_kernel(float* __restrict__ element, const int* __restrict__ flags) {
+  if (*flags != 0) *element = __builtin_nanf("");
 }
 
 static int fill_regions(Regions& r, const int64_t* off, const int64_t* len, int n, int n_total, const char* what) {
@@ -184,8 +195,20 @@ int cradle_grad_region_sumsq(const float* grads, const int64_t* region_off, cons
 
 int64_t cradle_adam_regions_workspace_floats(void) { return (int64_t)cradle::kMaxRegions * 512; }
 
+// Data-parallel ranks decide together whether an update is applied: a rank whose step rejected its input (flags != 0)
+// overwrites one gradient element with NaN before the gradients are summed over ranks, so that the squared norm
+// cradle_adam_step_regions works with is not finite on every rank and every rank skips.  element: any float of the
+// gradient arena that is summed after this call (the first of the bucket reduced at the end of the step).
+int cradle_grad_poison_if_flagged(float* element, const int* flags, hipStream_t stream) {
+  CRADLE_CHECK_ARG(element && flags, "grad_poison_if_flagged: null pointer");
+  hipLaunchKernelGGL(cradle::poison_if_flagged_kernel, dim3(1), dim3(1), 0, stream, element, flags);
+  CRADLE_CHECK_LAUNCH("grad_poison_if_flagged");
+  return CRADLE_OK;
+}
+
 // cradle_adam_step on the listed regions only, with the gradient's squared norm given as all_sums (device,
-// n_sums region sums of the whole arena, added in order).  norm_out (device float, may be NULL) receives |g'|.
+// n_sums region sums of the whole arena, added in order).  norm_out (device float[2], may be NULL): [0] receives
+// |g'|, [1] is incremented whenever the update is skipped (skip_flags set, or the squared norm not finite).
 int cradle_adam_step_regions(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                              const int64_t* region_off, const int64_t* region_len, int n_regions, const float* all_sums,
                              int n_sums, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

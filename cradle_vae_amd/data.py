@@ -83,6 +83,10 @@ class SparseDosage:
 
     def obs_per_dim(self) -> torch.Tensor:
         """(D != 0).sum(0) (perturbation_dataset.py:64)."""
+        if self.idx.is_cuda:
+            from . import ops
+
+            return ops.obs_counts_pairs(self.idx, self.val, self.n_treatments)
         hit = (self.idx >= 0) & (self.val != 0)
         return torch.bincount(self.idx[hit].long(), minlength=self.n_treatments)
 
@@ -105,6 +109,15 @@ def pack_counts(X: torch.Tensor, dtype="auto") -> torch.Tensor:
     return X.to(dtype)
 
 
+def _obs_counts(M: torch.Tensor) -> torch.Tensor:
+    """(M != 0).sum(0) (perturbation_dataset.py:64-65): a HIP reduction for a matrix in HBM, torch for one on the host."""
+    if M.is_cuda and M.dtype == torch.float32:
+        from . import ops
+
+        return ops.obs_counts_dense(M)
+    return (M != 0).sum(0)
+
+
 class TensorPerturbationDataset:
     """perturbation_dataset.py:44-82.  ``D`` may be dense (as in the reference) or a ``SparseDosage``."""
 
@@ -112,8 +125,8 @@ class TensorPerturbationDataset:
                  ids: Optional[Iterable] = None):
         self.X, self.D, self.qc, self.cfX = X, D, qc, cfX
         self.ids = np.arange(len(X)) if ids is None else np.array(ids)
-        self.D_obs_per_dim = self.D.obs_per_dim() if isinstance(D, SparseDosage) else (self.D != 0).sum(0)
-        self.qc_obs_per_dim = (self.qc != 0).sum(0)
+        self.D_obs_per_dim = self.D.obs_per_dim() if isinstance(D, SparseDosage) else _obs_counts(self.D)
+        self.qc_obs_per_dim = _obs_counts(self.qc)
         self.library_size = self.X.sum(1, dtype=torch.float32) if not self.X.is_floating_point() else self.X.sum(1)
 
     def __getitem__(self, idx) -> Dict[str, torch.Tensor]:
@@ -347,9 +360,21 @@ class DeviceBatchLoader:
             self.epoch += 1
 
 
+def _on_device(X: torch.Tensor) -> bool:
+    """A count matrix resident in HBM in one of the loader's storage types goes through the HIP kernels
+    (csrc/dataprep.hip); a matrix on the host is handled on the host, as the reference's data modules do."""
+    from . import ops
+
+    return X.is_cuda and X.dtype in ops.COUNT_TYPES and X.dim() == 2 and X.stride(1) == 1
+
+
 def batch_log_mean(X: torch.Tensor, step_size: int = 1 << 16) -> torch.Tensor:
     """mean over cells of log(X + 1) per gene (cradle_vae/data/utils/batch_statistics.py:4-10), in row
     slabs so that a data set resident in HBM needs no second copy."""
+    if _on_device(X):
+        from . import ops
+
+        return (ops.log_stats(X)[0] / X.shape[0]).float()
     total = torch.zeros(X.shape[1], device=X.device, dtype=torch.float32)
     for i in range(0, X.shape[0], step_size):
         total += torch.log(X[i:i + step_size].float() + 1).sum(0)
@@ -358,10 +383,29 @@ def batch_log_mean(X: torch.Tensor, step_size: int = 1 << 16) -> torch.Tensor:
 
 def batch_log_std(X: torch.Tensor, log_mean: torch.Tensor, correction: int = 1, step_size: int = 1 << 16) -> torch.Tensor:
     """std over cells of log(X + 1) per gene around ``log_mean`` (batch_statistics.py:13-23)."""
+    if _on_device(X):
+        from . import ops
+
+        centred = ops.log_stats(X, shift=log_mean.to(device=X.device, dtype=torch.float32).contiguous())[1]
+        return torch.sqrt(centred / (X.shape[0] - correction)).float()
     total = torch.zeros(X.shape[1], device=X.device, dtype=torch.float32)
     for i in range(0, X.shape[0], step_size):
         total += ((torch.log(X[i:i + step_size].float() + 1) - log_mean) ** 2).sum(0)
     return torch.sqrt(total / (X.shape[0] - correction))
+
+
+def log_mean_std(X: torch.Tensor, correction: int = 1):
+    """(batch_log_mean, batch_log_std) of a count matrix in HBM in ONE streaming pass (``cradle_log_stats``): sums of
+    y - y0 and (y - y0)^2, y = log(x + 1), around the first row's y0 -- the shift keeps the variance free of
+    cancellation (a gene that is constant over all cells gets std 0 exactly, as the reference's two passes give it)."""
+    from . import ops
+
+    n = X.shape[0]
+    shift = torch.log(X[0].float() + 1)
+    s = ops.log_stats(X, shift=shift)
+    mean = shift.double() + s[0] / n
+    var = torch.clamp(s[1] - s[0] * s[0] / n, min=0.0) / (n - correction)
+    return mean.float(), torch.sqrt(var).float()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -389,11 +433,32 @@ def build_counterfactual_inputs(X: torch.Tensor, treatment_codes: torch.Tensor, 
     """
     dev = X.device
     n, G = X.shape
-    cfX = torch.zeros((n, G), device=dev, dtype=X.dtype)
     codes = treatment_codes.to(dev)
     fail = qc_fail.to(dev).bool()
     source = X if reference_source is None else reference_source.to(dev)
     rank_among_fails = torch.cumsum(fail.long(), 0) - 1  # position of a failing cell within the split's failing cells
+    if _on_device(X) and source.dtype == X.dtype and source.is_contiguous() and n_peers <= 128:
+        # HBM-resident counts: the peers of every cell as one (n, n_peers) table of source rows (-1 = unused), then ONE
+        # launch of the segmented per-gene median kernel for the whole split (cradle_peer_median)
+        from . import ops
+
+        peers = torch.full((n, max(1, min(n_peers, 128))), -1, device=dev, dtype=torch.int32)
+        for t in torch.unique(codes).tolist():
+            members = torch.nonzero(codes == t).squeeze(1)
+            fails = torch.nonzero((codes == t) & fail).squeeze(1)
+            if fails.numel() == 0:
+                continue
+            k = min(n_peers, fails.numel())
+            if peer_index is not None:
+                pos = peer_index[t].to(dev)
+            else:
+                pos = torch.randint(0, fails.numel(), (members.numel(), k), device=dev, generator=generator)
+            sel = fails[pos]
+            if reference_source is not None:
+                sel = rank_among_fails[sel]
+            peers[members, :k] = sel.to(torch.int32)
+        return ops.peer_median(source, peers)
+    cfX = torch.zeros((n, G), device=dev, dtype=X.dtype)
     for t in torch.unique(codes).tolist():
         members = torch.nonzero(codes == t).squeeze(1)
         fails = torch.nonzero((codes == t) & fail).squeeze(1)
@@ -460,9 +525,12 @@ class TensorPerturbationDataModule:
                                               reference_source=self.X if cf_indexing == "reference" else None)
             self.datasets[split] = SCRNASeqTensorPerturbationDataset(Xs, self.D.rows(di), self.qc[di], cfX, ids=ids[idx.numpy()])
         Xtr = self.datasets["train"].X
-        log_mean = batch_log_mean(Xtr)
-        self.x_train_statistics = _stats_cls()(
-            x_mean=Xtr.mean(0), x_std=Xtr.std(0), log_x_mean=log_mean, log_x_std=batch_log_std(Xtr, log_mean))
+        if _on_device(Xtr):
+            log_mean, log_std = log_mean_std(Xtr)  # one pass over the train set
+        else:
+            log_mean = batch_log_mean(Xtr)
+            log_std = batch_log_std(Xtr, log_mean)
+        self.x_train_statistics = _stats_cls()(x_mean=Xtr.mean(0), x_std=Xtr.std(0), log_x_mean=log_mean, log_x_std=log_std)
         df = self.obs.groupby("treatment")["split"].agg(set).reset_index()
         for split in ("train", "val", "test"):
             df[split] = df["split"].apply(lambda s, split=split: split in s)

@@ -81,6 +81,14 @@ PROTOTYPES = {
          ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, i32, ctypes.c_float,
          ctypes.c_float, c_float_p, ctypes.c_void_p, c_stream],
     ),
+    "cradle_grad_poison_if_flagged": (i32, [c_float_p, ctypes.c_void_p, c_stream]),
+    "cradle_log_stats_workspace_doubles": (i64, [i64, i32]),
+    "cradle_log_stats": (i32, [ctypes.c_void_p, i32, i64, i32, i64, c_float_p, ctypes.c_void_p, i32, ctypes.c_void_p, i64,
+                               c_stream]),
+    "cradle_obs_counts_dense": (i32, [c_float_p, i64, i32, ctypes.c_void_p, c_stream]),
+    "cradle_obs_counts_pairs": (i32, [ctypes.c_void_p, c_float_p, i64, i32, i32, ctypes.c_void_p, c_stream]),
+    "cradle_peer_median": (i32, [ctypes.c_void_p, i32, i64, i32, ctypes.c_void_p, i64, i32, ctypes.c_void_p,
+                                 ctypes.c_void_p, c_stream]),
     "cradle_nb_sample_accumulate_ws": (
         i32,
         [c_float_p, i64, c_float_p, i32, c_float_p, c_float_p, c_float_p, i32, i32, i32, i32, i32, ctypes.c_uint64,
@@ -95,7 +103,7 @@ PROTOTYPES = {
 }
 
 MAX_LAYERS = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class MlpPtrs(ctypes.Structure):

@@ -13,7 +13,7 @@ from . import hip
 
 # Optional HIP-event timing of individual launches (bench.py: roofline of K1).  Events are
 # recorded on the stream the kernel is launched on (torch's current stream).
-KERNEL_TIMING = False
+KERNEL_TIMING = False  # True: K1 only (HIP events recorded by the C code); "all": also the _timed wrappers below
 KERNEL_TIMERS = []  # (name, hip.EventPair) for K1; (name, start_event, end_event) for _timed regions
 
 
@@ -22,13 +22,13 @@ class _timed:
         self.name = name
 
     def __enter__(self):
-        if KERNEL_TIMING:
+        if KERNEL_TIMING == "all":
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
             self.s.record()
 
     def __exit__(self, *exc):
-        if KERNEL_TIMING:
+        if KERNEL_TIMING == "all":
             self.e.record()
             KERNEL_TIMERS.append((self.name, self.s, self.e))
 
@@ -153,13 +153,14 @@ def nb_sample_accumulate(
     lib_ = hip.load()
     need = lib_.cradle_nb_sample_workspace_floats(P, C, G)
     ws = _sample_workspace(logits.device, need) if need > 0 else None
-    hip.check(
-        lib_.cradle_nb_sample_accumulate_ws(
-            _rp(logits), logits.stride(0), hip.ptr(lib), lib.numel(), hip.ptr(gene_consts), _rp(ksums),
-            _rp(samples), P, C, G, METHODS[method], SAMPLERS[sampler], seed & (2**64 - 1), row_offset & 0xFFFFFFFF,
-            hip.ptr(ws), need if ws is not None else 0, hip.stream()),
-        "nb_sample_accumulate",
-    )
+    with _timed("nb_sample_accumulate"):  # (bench.py: events on the launch stream around K9 and its partial-sum pass)
+        hip.check(
+            lib_.cradle_nb_sample_accumulate_ws(
+                _rp(logits), logits.stride(0), hip.ptr(lib), lib.numel(), hip.ptr(gene_consts), _rp(ksums),
+                _rp(samples), P, C, G, METHODS[method], SAMPLERS[sampler], seed & (2**64 - 1), row_offset & 0xFFFFFFFF,
+                hip.ptr(ws), need if ws is not None else 0, hip.stream()),
+            "nb_sample_accumulate",
+        )
     if not own_sums:
         sums += ksums
     return sums, samples
@@ -326,5 +327,74 @@ def gemm(
     if repeat > 1:
         hip.check(hip.load().cradle_gemm_f32_repeat(ctypes.byref(d), ws_ptr, ws_n, repeat, hip.stream()), "gemm_f32")
     else:
-        hip.check(hip.load().cradle_gemm_f32(ctypes.byref(d), ws_ptr, ws_n, hip.stream()), "gemm_f32")
+        with _timed(("gemm", M, N, K)):
+            hip.check(hip.load().cradle_gemm_f32(ctypes.byref(d), ws_ptr, ws_n, hip.stream()), "gemm_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# input preparation on the device (csrc/dataprep.hip)
+# ---------------------------------------------------------------------------------------------------------------
+COUNT_TYPES = {torch.float32: 0, torch.uint8: 1, torch.int16: 2, torch.int32: 3}
+
+
+def _counts(X: torch.Tensor):
+    if not X.is_cuda or X.dim() != 2 or X.stride(1) != 1 or X.dtype not in COUNT_TYPES:
+        raise hip.CradleHipError("expected a 2-D CUDA count matrix (fp32 / uint8 / int16 / int32) with unit column stride; "
+                                 f"got {X.dtype} on {X.device}")
+    return X.data_ptr(), COUNT_TYPES[X.dtype]
+
+
+def log_stats(X: torch.Tensor, shift: Optional[torch.Tensor] = None, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> (2, G) fp64: per-gene sum over the rows of X of y and y^2, y = log(x + 1) - shift[g] evaluated in fp32
+    (``cradle_log_stats``).  ``sums`` given: accumulated into (feed a matrix in row slabs)."""
+    ptr_, ty = _counts(X)
+    rows, G = X.shape
+    lib_ = hip.load()
+    accumulate = sums is not None
+    if sums is None:
+        sums = torch.empty((2, G), device=X.device, dtype=torch.float64)
+    if sums.shape != (2, G) or sums.dtype != torch.float64 or not sums.is_contiguous():
+        raise hip.CradleHipError("log_stats: sums must be a contiguous (2, G) fp64 tensor")
+    if rows == 0:
+        return sums if accumulate else sums.zero_()
+    need = lib_.cradle_log_stats_workspace_doubles(rows, G)
+    ws = torch.empty(need, device=X.device, dtype=torch.float64)
+    hip.check(lib_.cradle_log_stats(ptr_, ty, rows, G, X.stride(0), hip.ptr(shift), sums.data_ptr(), int(accumulate),
+                                    ws.data_ptr(), need, hip.stream()), "log_stats")
+    return sums
+
+
+def obs_counts_dense(M: torch.Tensor) -> torch.Tensor:
+    """(M != 0).sum(0) of a dense (rows, C) fp32 matrix -> (C,) int64."""
+    M = M.contiguous().float()
+    out = torch.empty(M.shape[1], device=M.device, dtype=torch.int64)
+    hip.check(hip.load().cradle_obs_counts_dense(hip.ptr(M), M.shape[0], M.shape[1], out.data_ptr(), hip.stream()),
+              "obs_counts_dense")
+    return out
+
+
+def obs_counts_pairs(idx: torch.Tensor, val: torch.Tensor, n_treatments: int) -> torch.Tensor:
+    """Per-treatment count of non-zero dosages of a matrix stored as (rows, kmax) (index, dosage) pairs -> (T,) int64."""
+    idx, val = idx.contiguous(), val.contiguous()
+    out = torch.empty(n_treatments, device=idx.device, dtype=torch.int64)
+    hip.check(hip.load().cradle_obs_counts_pairs(hip.ptr(idx), hip.ptr(val), idx.shape[0], idx.shape[1], n_treatments,
+                                                 out.data_ptr(), hip.stream()), "obs_counts_pairs")
+    return out
+
+
+def peer_median(src: torch.Tensor, peers: torch.Tensor) -> torch.Tensor:
+    """out[n, g] = lower median over the leading non-negative entries of peers[n] of src[peer, g] (``cradle_peer_median``);
+    a cell without peers gets a zero row.  src: stored counts, peers: (n, kmax) int32 rows of src, -1 = unused."""
+    ptr_, ty = _counts(src)
+    if not src.is_contiguous():
+        raise hip.CradleHipError("peer_median: src must be contiguous")
+    peers = peers.to(torch.int32).contiguous()
+    n, kmax = peers.shape
+    out = torch.empty((n, src.shape[1]), device=src.device, dtype=src.dtype)
+    flags = torch.zeros(1, device=src.device, dtype=torch.int32)
+    hip.check(hip.load().cradle_peer_median(ptr_, ty, src.shape[0], src.shape[1], peers.data_ptr(), n, kmax,
+                                            out.data_ptr(), flags.data_ptr(), hip.stream()), "peer_median")
+    if int(flags.item()) & 1:
+        raise hip.CradleHipError("peer_median: a peer index lies outside the source matrix")
     return out

@@ -154,6 +154,10 @@ class FusedElboStep:
         self.bucket_events = None
         self.bucket_events_used = None  # indices of ev_bucket the caller waits for (None: all three)
         self._checked_states = set()
+        # More than one data-parallel rank: a rank must not raise on its own (the others would wait for it in the next
+        # collective until the watchdog fires).  trainer.TrainStep sets this and checks on all ranks at once instead
+        # (TrainStep.check_flags: local flags + the count of updates every rank skipped, met in one small all-reduce).
+        self.defer_flag_check = False
         # Random draws of the step.  Default: the HIP step draws its own noise (Philox4x32-10 in one launch,
         # csrc/elementwise.hip draw_noise_kernel) keyed by these seeds -- seed_plated identical on every
         # data-parallel rank (mask, E, qc_E are shared latent variables), seed_local per rank (z_basal) -- and by
@@ -295,9 +299,11 @@ class FusedElboStep:
         # handed the same flags word, skips its update.  The host only has to say why, which costs a sync: on
         # the first call of every (P, N) state (a new loader), every 256th call, in forward-only (validation /
         # test) calls, and whenever trainer.fit finishes an epoch (check_flags).
-        if self._shape_key not in self._checked_states or self._calls % 256 == 0 or not compute_grads:
+        self.check_due = self._shape_key not in self._checked_states or self._calls % 256 == 0 or not compute_grads
+        if self.check_due:
             self._checked_states.add(self._shape_key)
-            self.check_flags()
+            if not self.defer_flag_check:
+                self.check_flags()
         return self.out
 
     def intermediate(self, name: str) -> torch.Tensor:

@@ -109,7 +109,8 @@ class TrainStep:
         lib = hip.load()
         self.region_ws = torch.zeros(lib.cradle_adam_regions_workspace_floats(), device=self.device)
         self.region_sums = torch.zeros(len(flat), device=self.device)
-        self.norm_out = torch.zeros(1, device=self.device)
+        self.norm_out = torch.zeros(2, device=self.device)  # [|g|, updates skipped on every rank since the last look]
+        self.fused.defer_flag_check = True  # ranks raise together (check_flags), never one alone inside FusedElboStep.run
 
     def _adam_regions(self, a, regions, all_sums):
         from . import hip
@@ -169,12 +170,19 @@ class TrainStep:
 
         gw, rk = self.piece_world, self.group_rank
         shard = self.grad_sync == "rs_ag"
+        # A rank whose step rejected its batch (flags != 0: invalid gradients) puts a NaN into the first element of
+        # what is summed at the end of the step; the squared norm is then not finite on EVERY rank and
+        # cradle_adam_step_regions skips the update everywhere -- no rank applies a sum that holds invalid gradients,
+        # and no rank updates alone.
+        lib = hip.load()
+        last = [s for (s, e), w in zip(self.buckets, self.bucket_waits) if w is None] if self.overlap else [0]
+        hip.check(lib.cradle_grad_poison_if_flagged(a.grad.data_ptr() + 4 * last[0], self.fused.flags.data_ptr(),
+                                                    hip.stream()), "cradle_grad_poison_if_flagged")
         if not self.overlap:
             parallel.allreduce_sum_(a.grad, self.world_size)  # one RCCL call on the flat gradient arena
         else:
             # buckets in the order the backward pass finishes them (decoder output layer, rest of the decoder, basal
             # encoder, the rest), each as soon as the event the step recorded for it has fired
-            lib = hip.load()
             ev = self.fused.bucket_events
             evs = (ev[0].begin, ev[0].end, ev[1].begin)
             waits = [None if i is None else evs[i] for i in self.bucket_waits]
@@ -205,9 +213,38 @@ class TrainStep:
             self._region_sumsq(a, self._all_regions, self.region_sums)
             self._adam_regions(a, self._all_regions, self.region_sums)
 
+    def check_flags(self):
+        """Raises -- on EVERY rank, in the same call -- if any rank's step rejected its input since the last look (a cell
+        with more than kmax dosages, qc outside {0,1}): such a step's update was skipped on all ranks.  One rank: the
+        fused step's own check.  Collective for N > 1: every rank must call it at the same point (the step does so
+        on its first call and every 256th; trainer.fit at the end of every epoch and after validation)."""
+        if self.fused is None:
+            return
+        if self.world_size == 1:
+            self.fused.check_flags()
+            return
+        from . import hip
+
+        mine = None
+        try:
+            self.fused.check_flags()
+        except hip.CradleHipError as e:
+            mine = str(e)
+        skipped = float(self.norm_out[1].item())
+        self.norm_out[1] = 0.0
+        t = torch.tensor([1.0 if mine else 0.0, skipped], device=self.device)
+        parallel._all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        if float(t[0]) > 0 or float(t[1]) > 0:
+            raise hip.CradleHipError(
+                f"rank {self.group_rank}: " + (mine or "another rank's step rejected its input") +
+                f"; {int(t[1])} parameter update(s) were skipped on all {self.world_size} ranks")
+
     def __call__(self, batch: Dict[str, torch.Tensor], n_particles: int) -> torch.Tensor:
         if self.fused is not None:
-            return self._fused_call(batch, n_particles)
+            loss = self._fused_call(batch, n_particles)
+            if self.world_size > 1 and self.fused.check_due:
+                self.check_flags()
+            return loss
         noise, cf_noise = self.draw_noise(n_particles, batch["X"].shape[0])
         self.optimizer.zero_grad(set_to_none=False)
         loss, metrics = self.lm.loss(
@@ -265,8 +302,7 @@ def fit(module, train_loader, val_loader=None, *, max_epochs: int = 1, max_steps
                 print(f"epoch {epoch} step {steps} train/loss {float(loss):.4f}", flush=True)
             if max_steps is not None and steps >= max_steps:
                 break
-        if stepper.fused is not None:
-            stepper.fused.check_flags()  # no epoch ends with a rejected batch unreported
+        stepper.check_flags()  # no epoch ends with a rejected batch unreported (all ranks raise together)
         record = {"epoch": epoch, "steps": steps, "train/loss": float(tot / max(cnt, 1)) if tot is not None else None}
         if val_loader is not None:
             module.eval()
@@ -275,6 +311,7 @@ def fit(module, train_loader, val_loader=None, *, max_epochs: int = 1, max_steps
                 v = module.validation_step(batch, vcnt).detach() * batch["X"].shape[0]
                 vtot = v if vtot is None else vtot + v
                 vcnt += batch["X"].shape[0]
+            stepper.check_flags()  # forward-only steps reject inputs too
             if vtot is not None:
                 t = torch.stack([vtot, torch.tensor(float(vcnt), device=vtot.device)])
                 parallel.allreduce_sum_(t, world)

@@ -296,7 +296,13 @@ int64_t cradle_adam_workspace_floats(void);
  *   cradle_grad_region_sumsq : region_sums[i] = sum_{region i} grads^2 for the n_regions listed regions (ws:
  *                              cradle_adam_regions_workspace_floats() floats)
  *   cradle_adam_step_regions : clip + Adam on the listed regions only; all_sums (device, n_sums = n_total) = the region
- *                              sums of the whole arena (all-gathered over ranks); norm_out (may be NULL) receives |g'| */
+ *                              sums of the whole arena (all-gathered over ranks); norm_out (device float[2], may be
+ *                              NULL): [0] receives |g'|, [1] is incremented whenever the update is skipped -- skip_flags
+ *                              non-zero, or the squared norm not finite
+ *   cradle_grad_poison_if_flagged : writes NaN into *element (a float of the gradient arena that is summed over ranks
+ *                              after this call) when *flags != 0.  With it a rank whose step rejected its input makes the
+ *                              squared norm non-finite on EVERY rank, so all ranks skip the update together: under
+ *                              Lightning DDP (train_norman.py:89-97) every rank applies the same update or none */
 int cradle_grad_region_sumsq(const float* grads, const int64_t* region_off, const int64_t* region_len, int n_regions,
                              int n_total, float* region_sums, float* ws, cradle_stream_t stream);
 int64_t cradle_adam_regions_workspace_floats(void);
@@ -305,6 +311,7 @@ int cradle_adam_step_regions(float* params, const float* grads, float* exp_avg, 
                              int n_sums, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                              float max_norm, float grad_scale, float* norm_out, const int* skip_flags,
                              cradle_stream_t stream);
+int cradle_grad_poison_if_flagged(float* element, const int* flags, cradle_stream_t stream);
 
 /* ---- K0: batch gather of the device-resident data source ------------------------------------
  * Replaces the DataLoader over TensorPerturbationDataset / SCRNASeqTensorPerturbationDataset
@@ -334,6 +341,31 @@ typedef struct cradle_batch_desc {
   int* present_out;              /* (1) or NULL */
 } cradle_batch_desc;
 int cradle_gather_batch(const cradle_batch_desc* desc, cradle_stream_t stream);
+
+/* ---- input preparation on the device (callers in front of the step) -------------------------
+ * cradle_log_stats: the train-set statistics of cradle_vae/data/utils/batch_statistics.py:4-23 (batch_log_mean /
+ * batch_log_std, two host-stepped passes there) as one streaming pass: with y = log(x + 1) - shift[g] in fp32,
+ *   sums[g] (+)= sum_rows y,   sums[G + g] (+)= sum_rows y^2     (fp64; accumulate != 0 adds to what sums holds, so a
+ * matrix can be fed in row slabs).  X: (rows, G) counts of type x_type (CRADLE_COUNTS_*), row stride ld; shift: (G) or
+ * NULL (zeros).  shift = log_mean gives batch_log_std's centred sum directly; shift = log(x_0 + 1) of any one row gives
+ * mean = shift + S1/n and var = (S2 - S1^2/n)/(n - 1) without cancellation.  workspace:
+ * cradle_log_stats_workspace_doubles(rows, G) doubles (partial sums, reduced in a fixed order: deterministic).
+ * cradle_obs_counts_dense / _pairs: counts[c] = #(rows with M[r, c] != 0) of a dense (rows, C) matrix, or of a
+ * dosage matrix stored as (rows, kmax) (treatment index, dosage) pairs, index -1 = unused -- the D_obs_per_dim /
+ * qc_obs_per_dim of cradle_vae/data/utils/perturbation_dataset.py:64-67.
+ * cradle_peer_median: out[n, g] = lower median (element of rank (k - 1) / 2, what torch.median returns) over the k
+ * leading non-negative entries of peers[n, 0..kmax) of src[peer, g]; k = 0 gives a zero row.  The counterfactual input
+ * cfX of cradle_vae/data/norman/data_module.py:175-191 (_get_cfX: X[idx].median(0) over <= 50 sampled QC-failing cells
+ * of the cell's treatment).  src, out: x_type storage; flags (device int): bit 0 is set when a peer index is >=
+ * src_rows (such a list is cut there, never dereferenced). */
+int64_t cradle_log_stats_workspace_doubles(int64_t rows, int G);
+int cradle_log_stats(const void* X, int x_type, int64_t rows, int G, int64_t ld, const float* shift, double* sums,
+                     int accumulate, double* workspace, int64_t workspace_doubles, cradle_stream_t stream);
+int cradle_obs_counts_dense(const float* M, int64_t rows, int C, int64_t* counts, cradle_stream_t stream);
+int cradle_obs_counts_pairs(const int* idx, const float* val, int64_t rows, int kmax, int T, int64_t* counts,
+                            cradle_stream_t stream);
+int cradle_peer_median(const void* src, int x_type, int64_t src_rows, int G, const int* peers, int64_t n_cells, int kmax,
+                       void* out, int* flags, cradle_stream_t stream);
 
 /* ---- K9: Gamma-Poisson observation sampler fused with the ATE accumulation ---------------
  * Replaces, per (particle p, condition t) row r = p*C + t of decoder logits:

@@ -424,6 +424,7 @@ def elbo_loss(
     metrics["cf_KLdivergence"] = kl.detach()  # :185
     inter = {
         "mask": g_s["mask"],
+        "cf_mask": cf_s["mask"],
         "E": g_s["E"],
         "qc_E": g_s["qc_E"],
         "z_basal": g_s["z_basal"],
@@ -500,3 +501,76 @@ def ate_from_draws(X_control: Tensor, X_alt: Tensor, method: str) -> Tensor:
         X_alt = torch.log2(1e4 * X_alt / X_alt.sum(dim=-1, keepdim=True) + 1)
     n = X_control.shape[0]
     return X_alt.sum(1) / n - X_control.sum(0, keepdim=True) / n
+
+
+@torch.no_grad()
+def model_average_treatment_effect(
+    params: Params,
+    *,
+    dosages_alt: Tensor,
+    dosages_control: Tensor,
+    quality: Tensor,
+    library_size: Tensor,
+    n_particles: int,
+    method: str,
+    batch_size: int = 500,
+    seed: int = 0,
+    max_alt: Optional[int] = None,
+    max_chunks: Optional[int] = None,
+) -> Tuple[Tensor, int]:
+    """estimate_model_average_treatment_effect as the reference writes it
+    (analysis/average_treatment_effects.py:78-203), every draw from torch's global generator in the
+    reference's order: per particle chunk one guide call for mask / E / qc_E (:143-148), one model call under
+    the control dosage (:157-162) and ONE MODEL CALL PER ALTERNATIVE PERTURBATION (:178-195), each with a fresh
+    prior draw of z_basal (model.py:112), both decoder variants and the Gamma -> Poisson draw of x_good AND
+    x_bad (model.py:128-132; only x_good is read, :190).
+
+    ``max_alt`` / ``max_chunks`` bound the work for timing (bench.py's cpu_baseline: a sample of the same
+    workload); the returned effects then cover that sample only.  -> ((n_alt_used, G) effects, model calls made)."""
+    assert method in ("mean", "perturbseq")  # :94-95
+    torch.manual_seed(seed)  # :92
+    dt = params["model.decoder.log_concentration"].dtype
+    T, L = params["model.p_E_loc"].shape
+    Q = params["model.p_qc_E_loc"].shape[0]
+    G = params["model.decoder.log_concentration"].shape[0]
+    n_alt = dosages_alt.shape[0] if max_alt is None else min(max_alt, dosages_alt.shape[0])
+    X_control_sum = torch.zeros((1, G), dtype=dt)
+    X_alt_sums = torch.zeros((n_alt, G), dtype=dt)
+    calls = 0
+
+    def model_call(D: Tensor, samples: Dict[str, Tensor], P: int) -> Tensor:
+        s = dict(samples)
+        s["z_basal"] = torch.randn((P, D.shape[0], L), dtype=dt)  # p_z_basal.sample (model.py:89,112)
+        if "E" not in s:  # the n_phenos probe call (:117-120) conditions on nothing: prior draws, model.py:101-112
+            s["E"] = params["model.p_E_loc"] + params["model.p_E_scale"] * torch.randn((P, T, L), dtype=dt)
+            s["mask"] = torch.bernoulli(params["model.p_mask_probs"].expand(P, T, L))
+            s["qc_E"] = params["model.p_qc_E_loc"] + params["model.p_qc_E_scale"] * torch.randn((P, Q, L), dtype=dt)
+        c, rate_good, rate_bad = model_decode(params, D, quality, s, library_size)
+        xs = []
+        for rate in (rate_good, rate_bad):  # model.py:131-132: pyro GammaPoisson.sample = Poisson(Gamma(c, rate))
+            lam = (torch._standard_gamma(c.expand_as(rate).contiguous()) / rate).clamp_(min=torch.finfo(dt).tiny)
+            xs.append(torch.poisson(lam))
+        return xs[0].squeeze(1)  # x_good (:171,190)
+
+    def transform(X: Tensor) -> Tensor:
+        if method == "perturbseq":  # :172-175
+            X = 1e4 * X / torch.sum(X, dim=1, keepdim=True)
+            X = torch.log2(X + 1)
+        return X
+
+    model_call(dosages_control, {}, 1)  # :117-120: one throw-away call to learn n_phenos; it consumes the generator
+    done = 0
+    for ci, i in enumerate(range(0, n_particles, batch_size)):
+        if max_chunks is not None and ci >= max_chunks:
+            break
+        P = min(batch_size, n_particles - i)
+        noise = dict(u_mask=torch.rand((P, T, L), dtype=dt), eps_E=torch.randn((P, T, L), dtype=dt),
+                     eps_qc_E=torch.randn((P, Q, L), dtype=dt))
+        _, g_s = guide_forward(params, noise, P)  # :143-148
+        X_control_sum[0] += transform(model_call(dosages_control, g_s, P)).sum(0)  # :157-176
+        calls += 1
+        for t_idx in range(n_alt):  # :178-195
+            X_alt_sums[t_idx] += transform(model_call(dosages_alt[t_idx:t_idx + 1], g_s, P)).sum(0)
+            calls += 1
+        done += P
+    return X_alt_sums / max(done, 1) - X_control_sum / max(done, 1), calls  # :199-201

@@ -84,6 +84,82 @@ def test_overlapped_bucket_allreduce_equals_single_allreduce():
         assert torch.allclose(d[0][0], c[0][0], rtol=1e-5, atol=1e-7), nb
 
 
+def _reject_worker(rank, port, out, overlap, sync, buckets):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo",
+                      CRADLE_OVERLAP_ALLREDUCE="1" if overlap else "0", CRADLE_GRAD_SYNC=sync, CRADLE_BUCKETS=buckets)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from cradle_vae_amd import hip
+        from cradle_vae_amd import synthetic as syn
+        from cradle_vae_amd.trainer import TrainStep
+        from tests import golden_io as gio
+        from tests.test_modular_gpu import build_loss_module
+
+        torch.cuda.set_device(0)
+        lm = build_loss_module(gio.load_elbo("mid", torch.float32, "cuda:0"))
+        lm.max_dosages_per_cell = 2
+        st = TrainStep(lm, lr=1e-3, world_size=WORLD, seed=7)
+        shape = syn.MID
+        good = syn.make_batch(shape, seed=50 + rank, device="cuda:0")
+        bad = dict(good)
+        if rank == 1:  # only this rank's batch is invalid: a cell with three dosages where the step plans for two
+            bad["D"] = good["D"].clone()
+            bad["D"][0] = 0.0
+            bad["D"][0, :3] = 1.0
+        for _ in range(2):
+            st(good, n_particles=shape.n_particles)
+        torch.cuda.synchronize()
+        before = [t.clone() for t in (st.fused.arena.flat, st.exp_avg, st.exp_avg_sq)]
+        loss_bad = st(bad, n_particles=shape.n_particles)  # (no host check on this call: the state was seen before)
+        torch.cuda.synchronize()
+        unchanged = all(torch.equal(a, b) for a, b in zip(before, (st.fused.arena.flat, st.exp_avg, st.exp_avg_sq)))
+        msg = None
+        try:
+            st.check_flags()
+        except hip.CradleHipError as e:
+            msg = str(e)
+        st(good, n_particles=shape.n_particles)
+        torch.cuda.synchronize()
+        moved = not torch.equal(before[0], st.fused.arena.flat)
+        st.check_flags()  # reported once; the valid step leaves nothing behind
+        out[rank] = (unchanged, msg, moved, bool(torch.isnan(loss_bad)), st.fused.arena.flat.detach().cpu().clone())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap,sync,buckets", [(True, "rs_ag", "1"), (True, "rs_ag", "2"), (True, "allreduce", "2"),
+                                                  (False, "allreduce", "1")])
+def test_a_batch_rejected_on_one_rank_is_skipped_on_all(overlap, sync, buckets):
+    """One rank's batch is invalid (more dosages in a cell than the step plans for): its gradients are garbage.  The
+    flags word is local, the summed gradients are not -- so the rejecting rank poisons its gradients with a NaN, the
+    squared norm is non-finite everywhere, and EVERY rank skips the update (parameters and moments bit-identical to
+    before, and across ranks); the host check then raises on both ranks in the same call, and training goes on."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_reject_worker, args=(r, port, out, overlap, sync, buckets)) for r in range(WORLD)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=150)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        assert sorted(out.keys()) == [0, 1], "a rank failed or hung"
+        res = {r: out[r] for r in range(WORLD)}
+    for r in range(WORLD):
+        unchanged, msg, moved, _, _ = res[r]
+        assert unchanged, f"rank {r} applied an update that held a rejected batch's gradients"
+        assert msg is not None and "skipped on all 2 ranks" in msg, (r, msg)
+        assert moved
+    assert "kmax" in res[1][1] and "another rank" in res[0][1]
+    assert res[1][3] and not res[0][3]  # the loss is NaN where the input was rejected, finite elsewhere
+    assert torch.equal(res[0][4], res[1][4]), "ranks diverged"
+
+
 def _rccl_worker(port, overlap, out, sync="allreduce"):
     """One rank, backend nccl (= RCCL): the data-parallel step exactly as bench.py --gpus N runs it,
     on the only GPU a test box has.  world_size 2 is what TrainStep is told, so the bucket events, the

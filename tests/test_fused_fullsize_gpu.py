@@ -22,8 +22,10 @@ from tests.test_modular_gpu import DEV, build_loss_module
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,kmax,seed", [("norman", 2, 19), ("replogle", 2, 18)])
+@pytest.mark.parametrize("name,kmax,seed", [("norman", 2, 19), ("replogle", 2, 18), ("adamson", 1, 18)])
 def test_fused_step_matches_oracle_at_full_size(name, kmax, seed):
+    """norman / replogle: see the module docstring.  adamson: demo/cradle_vae_adamson.yaml's sizes (L=100, basal encoder
+    hidden 200, beta 0.1, p0 0.001; one guide per cell, full treatment axis of T=90)."""
     from cradle_vae_amd import synthetic as syn
 
     worst = compare_with_oracle(syn.SHAPES[name], kmax, seed, compact=(name == "replogle"),
@@ -43,7 +45,25 @@ BARS = {  # per GEMM precision: relative L2 and max-scaled bars of every gradien
 }
 
 
-def compare_with_oracle(shape, kmax, seed, compact, precisions=("f32", "bf16x3")):
+def run_fused_announced(lm, case, treatments_present):
+    """run_fused through FusedElboStep.run with the loader's count of distinct treatments (cradle_step_desc.max_present):
+    what trainer.TrainStep does with a DeviceBatchLoader batch.  Same return values as run_fused."""
+    from cradle_vae_amd.step import OUT_KEYS
+
+    b, cfg = case["batch"], case["cfg"]
+    fs = lm._fused_step()
+    out = fs.run(X=b["X"], D=b["D"], D_obs_counts=b["D_obs_counts"], qc=b["qc"], qc_obs_counts=b["qc_obs_counts"],
+                 cfX=b["cfX"], library_size=b["library_size"], n_particles=cfg["n_particles"], noise=case["noise"],
+                 cf_noise=case["cf_noise"], treatments_present=treatments_present)
+    torch.cuda.synchronize()
+    fs.check_flags()
+    vals = out.clone()
+    by_id = {id(p): g.clone() for p, g in zip(fs.arena.params(), fs.arena.grad_views())}
+    grads = {k: by_id[id(p)] for k, p in lm.named_parameters()}
+    return vals[0], {k: vals[i] for i, k in enumerate(OUT_KEYS) if i > 0}, grads
+
+
+def compare_with_oracle(shape, kmax, seed, compact, precisions=("f32", "bf16x3"), announce_present=False):
     """One step of the fused path on a synthetic batch of `shape` against the fp64 oracle; the bars of the module
     docstring.  Returns the worst relative-L2 gradient error and the loss error per precision."""
     from cradle_vae_amd import synthetic as syn
@@ -86,7 +106,12 @@ def compare_with_oracle(shape, kmax, seed, compact, precisions=("f32", "bf16x3")
         lm = build_loss_module(case)
         lm.max_dosages_per_cell = kmax
         lm.precision = precision
-        loss, metrics, grads = run_fused(lm, case)
+        if announce_present:
+            present = int((b["D"] != 0).any(dim=0).sum())
+            loss, metrics, grads = run_fused_announced(lm, case, present)
+            assert lm._fused.desc.max_present == max(32, (present + 31) // 32 * 32) < lm._fused.desc.N * kmax
+        else:
+            loss, metrics, grads = run_fused(lm, case)
         d = lm._fused.desc
         assert (d.N * d.kmax < d.T) == compact  # Replogle runs the compact treatment axis
         assert d.precision == {"f32": 0, "bf16x3": 1, "bf16": 2}[precision]
@@ -105,3 +130,65 @@ def compare_with_oracle(shape, kmax, seed, compact, precisions=("f32", "bf16x3")
             worst[precision] = max(worst[precision], l2)
         worst[precision + "_loss"] = abs(float(loss.detach()) - float(ref_loss)) / abs(float(ref_loss))
     return worst
+
+
+def test_compact_axis_with_counted_treatments_matches_oracle():
+    """The scale-up configuration's regime at a size the dense fp64 oracle still holds: T = 3000 treatments >> N * kmax =
+    256 slots, one guide per cell, the loader's count of distinct treatments announced (cradle_step_desc.max_present:
+    the treatment axis is that count rounded up to 32) -- loss, terms and every gradient against the fp64 oracle."""
+    import dataclasses
+
+    from cradle_vae_amd import synthetic as syn
+
+    shape = dataclasses.replace(syn.SCALEUP, name="scaleup_reduced", n_cells=128, n_phenos=1500, n_treatments=3000,
+                                n_particles=3)
+    worst = compare_with_oracle(shape, 2, 41, compact=True, precisions=("f32",), announce_present=True)
+    print(f"\nscale-up regime, reduced: {worst}")
+
+
+def test_fused_equals_modular_at_the_scale_up_shape():
+    """BASELINE.json config 5's per-GPU step (N=512, P=5, G=8000, T=10 000, L=100; the dense fp64 oracle would need a
+    (T, T) one-hot through the embedding encoder: too big): the fused step with the compact treatment axis sized by the
+    loader's count against the modular HIP path, which evaluates all 10 000 treatments the way the reference does
+    (both guide passes, both decoder variants, autograd).  The modular path is pinned to the oracle by
+    tests/test_modular_gpu.py; the regime itself against the fp64 oracle by the reduced-size test above."""
+    from cradle_vae_amd import synthetic as syn
+    from oracle import cradle_oracle as co
+
+    shape = syn.SCALEUP
+    b = syn.make_batch(shape, seed=77, device=DEV)
+    cfg = dict(
+        n_latent=shape.n_latent, n_treatments=shape.n_treatments, n_phenos=shape.n_phenos, n_qc=shape.n_qc,
+        decoder_n_layers=shape.decoder_n_layers, decoder_n_hidden=shape.decoder_n_hidden,
+        basal_encoder_n_layers=shape.basal_encoder_n_layers, basal_encoder_n_hidden=shape.basal_encoder_n_hidden,
+        embedding_encoder_n_layers=shape.embedding_encoder_n_layers,
+        embedding_encoder_n_hidden=shape.embedding_encoder_n_hidden, mask_prior_prob=shape.mask_prior_prob,
+        embedding_prior_scale=1.0, beta=shape.beta, alpha=None, n_particles=shape.n_particles)
+    params = co.init_params(**{k: cfg[k] for k in cfg if k not in ("beta", "alpha", "n_particles")},
+                            log_x_mean=b["log_x_mean"].cpu(), log_x_std=b["log_x_std"].cpu(), seed=29)
+    params.pop("guide.treatment_one_hot")  # (T, T): the module keeps no eye(T) above T = 4096
+    case = dict(cfg=cfg, params={k: v.to(DEV) for k, v in params.items()}, batch=b,
+                noise=syn.make_noise(shape, 3, DEV), cf_noise=syn.make_noise(shape, 4, DEV))
+    lm = build_loss_module(case)
+    lm.max_dosages_per_cell = 2
+    present = int((b["D"] != 0).any(dim=0).sum())
+    loss_f, met_f, g_f = run_fused_announced(lm, case, present)
+    d = lm._fused.desc
+    assert d.T == 10000 and d.G == 8000 and d.max_present == (present + 31) // 32 * 32 < d.N * d.kmax < d.T
+    lm.step = "modular"
+    for p in lm.parameters():
+        p.grad = None
+    loss_m, met_m = lm.loss(
+        X=b["X"], D=b["D"], D_obs_counts=b["D_obs_counts"], qc=b["qc"], qc_obs_counts=b["qc_obs_counts"],
+        cfX=b["cfX"], condition_values={"library_size": b["library_size"]}, n_particles=cfg["n_particles"],
+        noise=case["noise"], cf_noise=case["cf_noise"])
+    loss_m.backward()
+    assert abs(float(loss_f) - float(loss_m)) <= 2e-5 * abs(float(loss_m)), (float(loss_f), float(loss_m))
+    for k in met_m:
+        assert abs(float(met_f[k]) - float(met_m[k])) <= 2e-5 * max(1.0, abs(float(met_m[k]))), k
+    for k, p in lm.named_parameters():
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        err = float((g_f[k] - ref).abs().max()) / max(float(ref.abs().max()), 1e-8)
+        assert err < 2e-3, (k, err)
+        l2 = float((g_f[k] - ref).norm()) / max(float(ref.norm()), 1e-12)
+        assert l2 < 1e-4, (k, l2)

@@ -100,3 +100,26 @@ def test_guide_samples_match_reference(name, tag, dtype, rtol):
         r = ref[k]
         err = float((s[k].detach().to(r.dtype) - r).abs().max()) / max(float(r.abs().max()), 1e-6)
         assert err <= 50 * rtol, (k, err)
+
+
+def test_sampled_ate_follows_the_references_draws():
+    """The "as written" ATE port (what bench.py times as the CPU baseline of the predictor) against the reference's own
+    estimate_model_average_treatment_effect run WITH its count draws under torch.manual_seed (fixture:
+    oracle/make_ate_sampled_golden.py): same generator, same consumption order -> the same effects, draw for draw.
+    (CPU generator streams are a property of the torch build; the fixture was written with the build in this image.)"""
+    import os
+
+    import numpy as np
+
+    z = np.load(os.path.join(gio.GOLDEN, "ate_sampled_tiny.npz"), allow_pickle=False)
+    params = {k[len("params/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("params/")}
+    T, Q = params["model.p_E_loc"].shape[0], params["model.p_qc_E_loc"].shape[0]
+    for method in ("mean", "perturbseq"):
+        for seed in (0, 5):
+            ref = torch.from_numpy(z[f"ate/{method}/seed{seed}"])
+            got, calls = co.model_average_treatment_effect(
+                params, dosages_alt=torch.from_numpy(z["D_alt"]), dosages_control=torch.from_numpy(z["D_control"]),
+                quality=torch.ones(1, Q), library_size=1e4 * torch.ones(1), n_particles=int(z["n_particles"]),
+                method=method, batch_size=int(z["chunk"]), seed=seed)
+            assert calls == 3 * (1 + ref.shape[0])  # 20 particles in chunks of 8: 3 chunks x (control + 4 alternatives)
+            assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (method, seed)
