@@ -28,13 +28,13 @@ import time
 # created in (1.17 ms instead of 0.95 ms per step with a process group merely alive; 0.95 ... 1.3 ms at 4-7 queues
 # depending on which stream the step runs on: profiles/r02_ddp_one_rank_emulation.txt).  16 gives every stream a queue
 # of its own.  The runtime reads the variable when it starts, so it is set before torch is imported.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("CRADLE_HW_QUEUES", "16")
-
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from cradle_vae_amd.env import set_hw_queues_for_multi_gpu  # noqa: E402  (imports nothing but os)
+
+set_hw_queues_for_multi_gpu()  # an existing GPU_MAX_HW_QUEUES is respected, CRADLE_HW_QUEUES must lie in 1..32
+
+import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
@@ -345,6 +345,52 @@ def secondary_shape(name, device, args, precision="f32"):
     return res
 
 
+def data_parallel_setup(lm, batch, shape, world, rank, dev_index, device, args):
+    """N > 1, before the warm-up: (1) every rank reports its device through one all-gather -- the first collective of
+    the run, so a communicator that does not span the ranks fails here, by name; (2) unless the environment pins it,
+    the gradient-exchange form is MEASURED instead of assumed: a few steps with one bucket after the step and with
+    the output layer's bucket reduced under the rest of the backward pass (CRADLE_BUCKETS = 1 / 2, trainer.TrainStep),
+    the faster one (max over ranks) is what the timed region runs.  One-rank emulation could not settle this
+    (the overlapped form stalls there); the ranks decide from the same all-reduced numbers."""
+    import torch.distributed as dist
+
+    from cradle_vae_amd import parallel
+    from cradle_vae_amd.trainer import TrainStep
+
+    mine = torch.tensor([rank, dev_index, torch.cuda.device_count()], device=device, dtype=torch.float32)
+    seen = parallel.all_gather_small(mine, world).view(world, 3).cpu().long().tolist()
+    info = {"backend": dist.get_backend(), "ranks": [{"rank": r, "device": d, "visible_devices": v} for r, d, v in seen],
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+    if "CRADLE_BUCKETS" in os.environ or os.environ.get("CRADLE_BENCH_AUTOTUNE", "1") == "0" or lm.step == "modular":
+        info["buckets"] = os.environ.get("CRADLE_BUCKETS", "1")
+        info["chosen_by"] = "environment"
+        return info
+    timings = {}
+    for nb in ("1", "2"):
+        os.environ["CRADLE_BUCKETS"] = nb
+        st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=world)
+        if st.fused is None:
+            break
+        for _ in range(3):
+            st(batch, n_particles=shape.n_particles)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            st(batch, n_particles=shape.n_particles)
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        parallel._all_reduce(t, op=dist.ReduceOp.MAX)
+        timings[nb] = float(t) / 10 * 1e3
+        trace(f"gradient exchange with CRADLE_BUCKETS={nb}: {timings[nb]:.3f} ms/step")
+        del st
+    best = min(timings, key=timings.get) if timings else "1"
+    os.environ["CRADLE_BUCKETS"] = best
+    info.update(buckets=best, chosen_by="measured before the warm-up (10 steps each, max over ranks)",
+                ms_per_step_by_buckets=timings)
+    return info
+
+
 def trace(msg):
     if os.environ.get("CRADLE_BENCH_TRACE"):
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
@@ -391,6 +437,9 @@ def main():
     lm.step = args.step_impl
     from cradle_vae_amd.trainer import TrainStep
 
+    dp_info = None
+    if world > 1:
+        dp_info = data_parallel_setup(lm, batch, shape, world, rank, dev_index, device, args)
     stepper = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=world)
 
     if stepper.fused is not None:
@@ -491,6 +540,8 @@ def main():
                             f"T={shape.n_treatments}, L={shape.n_latent}, H={shape.decoder_n_hidden}",
                 "step_impl": stepper.impl,
                 "decoder_variants_per_cell": V, "parallelism": f"dp{world}",
+                **({"data_parallel": dict(dp_info, grad_sync=getattr(stepper, "grad_sync", None),
+                                          overlap=getattr(stepper, "overlap", None))} if dp_info else {}),
                 "treatment_slots": treatment_slots(shape, lm, batch),
                 "loss": float(loss),
             },

@@ -5,17 +5,10 @@
 #include "common.h"
 #include "kernels.h"
 #include "philox.h"
+#include "gauss_math.h"
 
 namespace cradle {
 
-constexpr float kEps32 = 1.1920928955078125e-07f;  // torch.finfo(float32).eps: clamp_probs
-constexpr float kVarEps = 1e-4f;                   // mlp.py:227
-
-__device__ __forceinline__ float clamp_probs(float p) { return fminf(fmaxf(p, kEps32), 1.0f - kEps32); }
-__device__ __forceinline__ bool interior(float p) { return p > kEps32 && p < 1.0f - kEps32; }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
-__device__ __forceinline__ bool finitef_(float x) { return fabsf(x) <= 3.4028234663852886e38f; }
 
 // =====================================================================================
 // The step's own noise: every random draw of one ELBO step in one launch.  The reference draws with torch's
@@ -694,23 +687,6 @@ int mask_bwd(const float* logits, const float* p_mask_probs, float tau, const fl
 //   var = nan_to_num(|exp(lv)+1e-4|), mean = nan_to_num(mean_raw), sd = sqrt(var), s = mean + sd*eps
 //   log N(ploc,pscale)(s) - log N(mean,sd)(s) = -(s-ploc)^2/(2 pscale^2) - log pscale + eps^2/2 + log sd
 // =====================================================================================
-struct GaussVals {
-  float mean, sd, e;
-  bool mean_ok, var_ok;
-};
-__device__ __forceinline__ GaussVals gauss_vals(float mean_raw, float lv_raw) {
-  GaussVals g;
-  g.e = expf(lv_raw);
-  const float var_raw = fabsf(g.e + kVarEps);
-  g.var_ok = finitef_(var_raw) && !(var_raw != var_raw);
-  g.mean_ok = finitef_(mean_raw) && !(mean_raw != mean_raw);
-  g.mean = nan_to_num_ref(mean_raw);
-  g.sd = sqrtf(nan_to_num_ref(var_raw));
-  return g;
-}
-
-// The draw itself, written once so that every kernel that needs E[p,t,l] gets the same bits.
-__device__ __forceinline__ float gauss_draw(const GaussVals& g, float ep) { return fmaf(g.sd, ep, g.mean); }
 
 // q(E|M): rows = PP*Tc (particle, slot).  Off the critical path: the gather that feeds the encoders
 // (gather_offsets_kernel) evaluates the draws it needs itself; this kernel keeps E, sd and the
@@ -756,12 +732,6 @@ int gaussE_fwd(const float* heads, const float* eps, const float* ploc, const fl
   return CRADLE_OK;
 }
 
-__device__ __forceinline__ void gauss_head_grads(const GaussVals& g, float ds, float ep, float c_over_sd, float& dmean,
-                                                 float& dlv) {
-  dmean = g.mean_ok ? ds : 0.f;
-  const float dsd = ds * ep + c_over_sd;
-  dlv = g.var_ok ? dsd * g.e / (2.0f * g.sd) : 0.f;
-}
 
 // Backward of q(E|M) fused with the scatter that produces its incoming gradient: one workgroup per
 // (slot, particle) first sums d(mask*E)[pp,t,:] = sum_{cells n of t} D[n,t] * g[pp,n,:] over the CSC

@@ -155,6 +155,22 @@ int finalize_loss(const float* recon, const float* wrec, const float* ltz, const
                   const float* SE, const float* Sq, const float* cw, const float* cwq, float beta, int P, int N, int T,
                   int Q, const int* flags, float* out, hipStream_t stream);
 
+// ---- qc_chain.hip : q(qc_E) (Q rows through an MLP) as single-workgroup launches
+bool qc_chain_supported(int Q, int L, int Hm, int He, int Hd, int PP);
+// every layer, the heads, the draws + log-ratio sums S, qsum, vq = qc_E . Wqc^T (PP*Q, He), wq = qsum . Wbad^T (P, Hd)
+int qc_chain_fwd(const cradle_mlp_ptrs& m, float* const* y, float* const* r, float* heads, const float* eps, const float* ploc,
+                 const float* pscale, float* qcE, float* sd, float* S, float* qsum, const float* Wqc, int64_t ldwqc, float* vq,
+                 const float* Wbad, int64_t ldwbad, float* wq, int Q, int L, int Hm, int He, int Hd, int PP, int P,
+                 hipStream_t stream);
+// d qc_E = dvq . Wqc (+ dwq . Wbad for the main pass), the Gaussian head's backward, the data-gradient chain (da[k] left
+// in HBM), every bias and weight gradient of the qc encoder.  dWqc / dWbad: NULL (the caller makes them) or where
+// dvq^T qc_E / dwq^T qsum go.
+int qc_chain_bwd(const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, float* const* y, float* const* r, float* const* da,
+                 const float* heads, float* dheads, const float* eps, const float* ploc, const float* pscale, const float* qcE,
+                 const float* sd, const float* coefQ, const float* dvq, const float* dwq, const float* qsum, const float* Wqc,
+                 int64_t ldwqc, float* dWqc, const float* Wbad, int64_t ldwbad, float* dWbad, int Q, int L, int Hm, int He,
+                 int Hd, int PP, int P, hipStream_t stream);
+
 // ---- adam.hip
 int adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int step, float max_norm, float grad_scale, float* norm_ws,

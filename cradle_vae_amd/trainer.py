@@ -65,13 +65,18 @@ class TrainStep:
                 self.grad_sync = "allreduce"
             if world_size > 1:
                 self._setup_regions(a, shardable)
-                if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
-                    import warnings
+                import warnings
 
+                queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+                if queues < 6:  # measured (profiles/r02_ddp_one_rank_emulation.txt): 6 and more run at full speed
                     warnings.warn("multi-GPU step with GPU_MAX_HW_QUEUES=%s: the step's streams share hardware queues "
                                   "with the communicator's and run one after the other (0.2-0.3 ms per step); export "
                                   "GPU_MAX_HW_QUEUES=16 before the process starts (bench.py and train.py do)"
                                   % os.environ.get("GPU_MAX_HW_QUEUES", "4 (the runtime's default)"))
+                if queues >= 8 and int(os.environ.get("CRADLE_BUCKETS", "1")) > 1:
+                    warnings.warn("CRADLE_BUCKETS > 1 with GPU_MAX_HW_QUEUES >= 8: in the one-rank emulation on this "
+                                  "runtime every form that reduces a bucket on the communication stream took twice "
+                                  "the step time in that combination (DESIGN 6); measure before relying on it")
             if self.overlap:
                 self.fused.bucket_events = (hip.EventPair(), hip.EventPair())
                 self.fused.bucket_events_used = {i for i in self.bucket_waits if i is not None}

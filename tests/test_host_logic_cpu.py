@@ -472,3 +472,27 @@ def test_checkpoint_in_the_references_layout_loads_strictly(tmp_path):
     for k, v in mod.state_dict().items():
         assert torch.equal(v, case["state_dict"][k]), k
     assert mod.predictor.guide is mod.loss_module.guide and mod.predictor.model is mod.loss_module.model
+
+
+def test_hardware_queue_setting_respects_the_environment():
+    """cradle_vae_amd.env: sixteen hardware queues for N > 1 unless the user chose (GPU_MAX_HW_QUEUES is never overwritten),
+    CRADLE_HW_QUEUES validated against the runtime's 1..32."""
+    import pytest
+
+    from cradle_vae_amd.env import set_hw_queues_for_multi_gpu as setq
+
+    env = {"WORLD_SIZE": "1"}
+    setq(env)
+    assert "GPU_MAX_HW_QUEUES" not in env  # one GPU: HIP's default
+    env = {"WORLD_SIZE": "8"}
+    setq(env)
+    assert env["GPU_MAX_HW_QUEUES"] == "16"
+    env = {"WORLD_SIZE": "8", "GPU_MAX_HW_QUEUES": "6", "CRADLE_HW_QUEUES": "12"}
+    setq(env)
+    assert env["GPU_MAX_HW_QUEUES"] == "6"
+    env = {"WORLD_SIZE": "2", "CRADLE_HW_QUEUES": "12"}
+    setq(env)
+    assert env["GPU_MAX_HW_QUEUES"] == "12"
+    for bad in ("0", "33", "many"):
+        with pytest.raises(ValueError):
+            setq({"WORLD_SIZE": "2", "CRADLE_HW_QUEUES": bad})

@@ -27,8 +27,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # N > 1: sixteen hardware queues per process instead of HIP's four, set before the runtime starts (see bench.py)
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("CRADLE_HW_QUEUES", "16")
+from cradle_vae_amd.env import set_hw_queues_for_multi_gpu  # noqa: E402  (imports nothing but os)
+
+set_hw_queues_for_multi_gpu()
 
 RESULTS_BASE_DIR = "results/"
 
