@@ -267,7 +267,7 @@ class TrainStep:
 
 
 def fit(module, train_loader, val_loader=None, *, max_epochs: int = 1, max_steps: Optional[int] = None,
-        gradient_clip_val: Optional[float] = 100.0, seed: int = 0, log_every: int = 0, callbacks=()):
+        gradient_clip_val: Optional[float] = 100.0, seed: int = 0, log_every: int = 0, callbacks=(), step_callbacks=()):
     """What ``pl.Trainer(...).fit(lightning_module, datamodule)`` does in train_norman.py:89-104
     for this module, without pytorch_lightning: epochs over ``train_loader`` with ``TrainStep``
     (fused HIP step + RCCL all-reduce + clip + Adam), then ``validation_step`` over
@@ -276,7 +276,9 @@ def fit(module, train_loader, val_loader=None, *, max_epochs: int = 1, max_steps
     ``module`` is a ``PerturbationLightningModule``; loaders yield batch dicts on the module's
     device (``cradle_vae_amd.data.DeviceBatchLoader``).  ``callbacks``: callables
     ``cb(module, epoch, record)`` run after each epoch (checkpointing, early stopping by raising
-    StopIteration)."""
+    StopIteration); every key of ``record`` is the same on all ranks (train/loss and val/loss are all-reduced), so
+    ranks that act on it act alike.  ``step_callbacks``: callables ``cb(module, epoch, steps)`` run after every training
+    step (ModelCheckpoint(every_n_train_steps=...), train_norman.py:240-247)."""
     from . import parallel
 
     world, _ = parallel.world_and_rank()
@@ -305,10 +307,18 @@ def fit(module, train_loader, val_loader=None, *, max_epochs: int = 1, max_steps
             steps += 1
             if log_every and steps % log_every == 0:
                 print(f"epoch {epoch} step {steps} train/loss {float(loss):.4f}", flush=True)
+            for cb in step_callbacks:
+                cb(module, epoch, steps)
             if max_steps is not None and steps >= max_steps:
                 break
         stepper.check_flags()  # no epoch ends with a rejected batch unreported (all ranks raise together)
-        record = {"epoch": epoch, "steps": steps, "train/loss": float(tot / max(cnt, 1)) if tot is not None else None}
+        train_loss = None
+        if tot is not None or world > 1:  # the mean over every rank's steps: a monitored key must not be rank-local
+            t = torch.stack([tot if tot is not None else torch.zeros((), device=stepper.device),
+                             torch.tensor(float(cnt), device=stepper.device)])
+            parallel.allreduce_sum_(t, world)
+            train_loss = float(t[0] / t[1]) if float(t[1]) > 0 else None
+        record = {"epoch": epoch, "steps": steps, "train/loss": train_loss}
         if val_loader is not None:
             module.eval()
             vtot, vcnt = None, 0

@@ -68,7 +68,7 @@ class Checkpointing:
     def __init__(self, results_dir, patience=50, every_n_train_steps=2000, rank=0):
         self.dir = join(results_dir, "checkpoints")
         self.patience, self.every, self.rank = patience, every_n_train_steps, rank
-        self.best, self.best_model_path, self.bad_epochs, self.last_periodic = None, None, 0, 0
+        self.best, self.best_model_path, self.bad_epochs = None, None, 0
         self.rows = []
         if rank == 0:
             os.makedirs(self.dir, exist_ok=True)
@@ -88,11 +88,16 @@ class Checkpointing:
                 save_checkpoint(module, self.best_model_path)
         else:
             self.bad_epochs += 1
-        if self.rank == 0 and steps // self.every > self.last_periodic:
-            self.last_periodic = steps // self.every
-            save_checkpoint(module, join(self.dir, f"epoch={epoch}-step={steps}-val_loss={key:.2f}.ckpt"))
         if self.bad_epochs >= self.patience:
-            raise StopIteration  # EarlyStopping(monitor="val/loss", patience=...)
+            raise StopIteration  # EarlyStopping(monitor="val/loss", patience=...): the key is the same on every rank
+
+    def on_train_step(self, module, epoch, steps):
+        """ModelCheckpoint(every_n_train_steps=2000) of train_norman.py:240-247: fires inside an epoch too."""
+        from cradle_vae_amd.lightning_module import save_checkpoint
+
+        if self.rank == 0 and self.every and steps % self.every == 0:
+            key = float("nan") if self.best is None else self.best
+            save_checkpoint(module, join(self.dir, f"epoch={epoch}-step={steps}-val_loss={key:.2f}.ckpt"))
 
 
 def train(config, data_namespace=None, results_base=None, patience=50, quiet=False):
@@ -141,8 +146,15 @@ def train(config, data_namespace=None, results_base=None, patience=50, quiet=Fal
     max_steps = config.get("max_steps", -1)
     hist = fit(module, data_module.train_dataloader(), data_module.val_dataloader(),
                max_epochs=config.get("max_epochs") or 1000, max_steps=None if max_steps in (None, -1) else max_steps,
-               gradient_clip_val=config.get("gradient_clip_norm"), seed=config.get("seed", 0), callbacks=(ckpt,))
+               gradient_clip_val=config.get("gradient_clip_norm"), seed=config.get("seed", 0), callbacks=(ckpt,),
+               step_callbacks=(ckpt.on_train_step,))
     val_iwelbo, best = None, ckpt.best_model_path
+    if world > 1:
+        # the evaluation of the best checkpoint below is rank 0's alone (100-particle IWELBO over the validation set:
+        # minutes on a large one).  The other ranks have nothing left to exchange: the group is dissolved here, after
+        # one last barrier, rather than left waiting in a collective whose watchdog would fire
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank == 0:
         with open(join(results_dir, "metrics.csv"), "w", newline="") as f:  # CSVLogger's file
             keys = sorted({k for r in hist for k in r})
@@ -163,8 +175,6 @@ def train(config, data_namespace=None, results_base=None, patience=50, quiet=Fal
         if not quiet:
             print(json.dumps({"results_dir": results_dir, "epochs": len(hist), "best_checkpoint_path": best,
                               "val/loss": ckpt.best, "val/IWELBO": val_iwelbo}), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
     return val_iwelbo, results_dir
 
 
