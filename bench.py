@@ -155,6 +155,7 @@ def loss_parity(lm, shape, batch, device):
         P, T, L = shape.n_particles, shape.n_treatments, shape.n_latent
         mask = fs.intermediate("mask").view(2 * P, T, L).cpu().double()
         flips = int((mask[:P] != inter["mask"]).sum()) + int((mask[P:] != inter["cf_mask"]).sum())
+    terms["oracle_values"] = {k: float(v) for k, v in ref_metrics.items()}
     return abs(float(loss) - float(ref)) / abs(float(ref)), terms, flips
 
 
@@ -340,6 +341,7 @@ def secondary_shape(name, device, args, precision="f32"):
                         "bf16 (operands rounded to bf16, fp32 accumulate)") + " in the GEMMs of >= 1 GFLOP; f32 elsewhere"
         if not args.no_cpu_baseline:
             rel, terms, flips = loss_parity(lm, shape, batch, device)
+            terms.pop("oracle_values")
             res["loss_rel_err_vs_oracle"], res["loss_terms_max_rel_err_vs_oracle"] = rel, max(terms.values())
             res["mask_bits_differing_from_oracle"] = flips
     return res
@@ -564,6 +566,7 @@ def main():
             if stepper.fused is not None:
                 rel, terms, flips = loss_parity(lm, shape, batch, device)
                 out["loss_rel_err_vs_oracle"] = rel
+                out["loss_terms_oracle_values"] = terms.pop("oracle_values")
                 out["loss_terms_max_rel_err_vs_oracle"] = max(terms.values())
                 out["loss_terms_rel_err_vs_oracle"] = terms
                 out["mask_bits_differing_from_oracle"] = flips

@@ -928,15 +928,26 @@ __global__ __launch_bounds__(256) void zhead_fwd_kernel(const float* __restrict_
       if (cf) {
         const GaussVals g2 = gauss_vals(m2[e], v2[e]);
         const GaussVals g1 = gauss_vals(m1[e], v1[e]);
-        const float lv1 = 2.0f * logf(g1.sd), lv2 = 2.0f * logf(g2.sd);
+        // d = lv1 - lv2 = log(var1 / var2).  The two encoder passes see nearly the same input early in training, so
+        // d and dmu are small and 1 + d - exp(d) = -(d^2/2 + d^3/6 + ...) is a difference of numbers near 1: written
+        // as the reference does, every element carries an fp32 rounding error of ~1e-7 against a value of ~d^2/2, and
+        // the sum over cells x latents (the KL is a SUM, loss_modules.py:190-196) sat 6e-5 .. 1.5e-4 off the fp64
+        // value.  Same quantity, evaluated without the cancellation (log1p of the relative variance difference, the
+        // series of d - expm1(d) for small d).
+        const float var1 = g1.sd * g1.sd, var2 = g2.sd * g2.sd;
+        const float d = log1pf((var1 - var2) / var2);
         const float dmu = g1.mean - g2.mean;
-        const float ratio = expf(lv1 - lv2);
-        a_kl += -0.5f * (1.0f + lv1 - lv2 - dmu * dmu - ratio);
+        const float em1 = expm1f(d);  // ratio - 1
+        const float one_d_ratio =
+            fabsf(d) < 0.3f
+                ? -d * d * (0.5f + d * (1.0f / 6 + d * (1.0f / 24 + d * (1.0f / 120 + d * (1.0f / 720 + d * (1.0f / 5040))))))
+                : d - em1;
+        a_kl += -0.5f * (one_d_ratio - dmu * dmu);
         // d/d(mean), d/d(lv) then lv = log(exp(lv_raw) + 1e-4): d lv / d lv_raw = e / var
         dm1[e] = g1.mean_ok ? kl_coef * dmu : 0.f;
         dm2[e] = g2.mean_ok ? -kl_coef * dmu : 0.f;
-        dv1[e] = g1.var_ok ? kl_coef * (-0.5f) * (1.0f - ratio) * g1.e / (g1.sd * g1.sd) : 0.f;
-        dv2[e] = g2.var_ok ? kl_coef * (-0.5f) * (ratio - 1.0f) * g2.e / (g2.sd * g2.sd) : 0.f;
+        dv1[e] = g1.var_ok ? kl_coef * 0.5f * em1 * g1.e / var1 : 0.f;
+        dv2[e] = g2.var_ok ? kl_coef * (-0.5f) * em1 * g2.e / var2 : 0.f;
       }
     }
     stv<V>(z + r0 * ldz + l, zv);
