@@ -115,7 +115,8 @@ def estimate_model_average_treatment_effect(
                 z = z_shared.expand(c, n, L)
             else:  # p_z_basal = Normal(0, 1) drawn per call (model.py:82)
                 z = torch.randn((c, n, L), device=device, generator=gen)
-            off = F_hip.dosage_matmul(plan.rows(s0, s1), EM, c) if plan is not None else torch.matmul(D_all[s0:s1], EM)
+            off = (F_hip.dosage_matmul(plan.rows(s0, s1), EM, c) if plan is not None
+                   else F_hip.dense_dosage_matmul(D_all[s0:s1], EM, c))
             z_good = torch.cat([z, off, torch.zeros((c, n, L), device=device)], dim=-1)  # model.py:121
             p_x_good = model.decoder(z_good, lib)
             call_seed = (seed * 7919 + ci) * 4099 + s0

@@ -45,7 +45,7 @@ int cradle_struct_layout(const char* name, int64_t* out, int max_entries) {
     PUT(sizeof(S));
     OFF(S, N); OFF(S, G); OFF(S, T); OFF(S, Q); OFF(S, kmax); OFF(S, x_type); OFF(S, cfx_type); OFF(S, pos); OFF(S, X);
     OFF(S, cfX); OFF(S, qc); OFF(S, library_size); OFF(S, d_idx); OFF(S, d_val); OFF(S, d_dense); OFF(S, X_out);
-    OFF(S, cfX_out); OFF(S, qc_out); OFF(S, lib_out); OFF(S, D_out); OFF(S, present_out);
+    OFF(S, cfX_out); OFF(S, qc_out); OFF(S, lib_out); OFF(S, D_out); OFF(S, present_out); OFF(S, rows); OFF(S, flags);
     return n;
   }
   if (!strcmp(name, "cradle_gemm_desc")) {

@@ -39,7 +39,11 @@ __device__ __forceinline__ void convert_any(const void* src, int type, int64_t r
 
 __global__ __launch_bounds__(256) void gather_batch_kernel(const cradle_batch_desc d) {
   const int n = blockIdx.x;
-  const int64_t row = d.pos[n];
+  int64_t row = d.pos[n];
+  if (d.rows > 0 && (row < 0 || row >= d.rows)) {  // a stale or oversized index: reported, not followed
+    if (threadIdx.x == 0 && d.flags) atomicOr(d.flags, 1);
+    row = 0;
+  }
   convert_any(d.X, d.x_type, row, d.X_out + (int64_t)n * d.G, d.G);
   convert_any(d.cfX, d.cfx_type, row, d.cfX_out + (int64_t)n * d.G, d.G);
   for (int q = threadIdx.x; q < d.Q; q += blockDim.x) d.qc_out[(int64_t)n * d.Q + q] = d.qc[row * d.Q + q];
@@ -64,15 +68,19 @@ __global__ __launch_bounds__(1024) void count_present_kernel(const cradle_batch_
   for (int w = threadIdx.x; w < words; w += 1024) bits[w] = 0u;
   if (threadIdx.x == 0) total = 0;
   __syncthreads();
+  auto stored_row = [&](int n) {
+    const int64_t r = d.pos[n];
+    return (d.rows > 0 && (r < 0 || r >= d.rows)) ? (int64_t)0 : r;
+  };
   if (d.d_dense) {
     const int64_t n_el = (int64_t)d.N * d.T;
     for (int64_t i = threadIdx.x; i < n_el; i += 1024) {
       const int t = (int)(i % d.T);
-      if (d.d_dense[d.pos[i / d.T] * d.T + t] != 0.f) atomicOr(&bits[t >> 5], 1u << (t & 31));
+      if (d.d_dense[stored_row((int)(i / d.T)) * d.T + t] != 0.f) atomicOr(&bits[t >> 5], 1u << (t & 31));
     }
   } else {
     for (int i = threadIdx.x; i < d.N * d.kmax; i += 1024) {
-      const int64_t e = d.pos[i / d.kmax] * d.kmax + i % d.kmax;
+      const int64_t e = stored_row(i / d.kmax) * d.kmax + i % d.kmax;
       const int t = d.d_idx[e];
       if (t >= 0 && t < d.T && d.d_val[e] != 0.f) atomicOr(&bits[t >> 5], 1u << (t & 31));
     }
@@ -99,6 +107,11 @@ extern "C" int cradle_gather_batch(const cradle_batch_desc* d, hipStream_t strea
   CRADLE_CHECK_ARG((d->d_dense != nullptr) != (d->d_idx != nullptr && d->d_val != nullptr && d->kmax > 0),
                    "gather_batch: give either dense dosages or (index, value) pairs with kmax > 0");
   CRADLE_CHECK_ARG(d->x_type >= 0 && d->x_type <= 3 && d->cfx_type >= 0 && d->cfx_type <= 3, "gather_batch: bad count type");
+  CRADLE_CHECK_ARG(d->rows >= 0, "gather_batch: rows=%lld is negative", (long long)d->rows);
+  if (d->flags && hipMemsetAsync(d->flags, 0, sizeof(int), stream) != hipSuccess) {
+    cradle_set_error("gather_batch: clearing the flags word failed");
+    return CRADLE_ERR_HIP;
+  }
   hipLaunchKernelGGL(gather_batch_kernel, dim3(d->N), dim3(256), 0, stream, *d);
   CRADLE_CHECK_LAUNCH("gather_batch_kernel");
   if (d->present_out) {

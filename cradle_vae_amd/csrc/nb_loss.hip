@@ -16,6 +16,8 @@
 #include "common.h"
 #include "nb_math.h"
 
+#include <mutex>
+
 namespace cradle {
 
 // TAIL: the gene count is not a multiple of 4 (Gv < G): the last 16-byte vector of a row is masked.  A separate
@@ -423,22 +425,28 @@ int64_t cradle_nb_workspace_floats(int P, int N, int G) {
 namespace {
 constexpr int64_t kStaticScratchFloats = 4ll << 20;  // 16 MiB per GPU: e.g. 512 cells x 8192 genes
 static __device__ __align__(256) float scratch[kStaticScratchFloats];
-float* g_scratch_ptr[16] = {};  // per device: each GPU holds its own copy of the array at its own address
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices] = {};  // per device: each GPU holds its own copy of the array at its own address
+hipError_t g_scratch_err[kMaxDevices] = {};
+std::once_flag g_scratch_once[kMaxDevices];
 
+// The address of `scratch` on the current device, looked up once per device (std::call_once: two host threads may
+// make a device's first call together).  hipGetSymbolAddress resolves the code object's symbol lazily and is not
+// legal under stream capture: a caller that captures calls cradle_nb_static_init() once per device beforehand.
 int static_scratch(float** out) {
   int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
-    cradle_set_error("nb_logprob_fwd_bwd_static: cannot identify the current device");
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    cradle_set_error("nb_logprob_fwd_bwd_static: cannot identify the current device (ordinals 0..%d)", kMaxDevices - 1);
     return CRADLE_ERR_HIP;
   }
-  if (!g_scratch_ptr[dev]) {
+  std::call_once(g_scratch_once[dev], [dev] {
     float* p = nullptr;
-    const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
-    if (e != hipSuccess || !p) {
-      cradle_set_error("nb_logprob_fwd_bwd_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
-      return CRADLE_ERR_HIP;
-    }
+    g_scratch_err[dev] = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
     g_scratch_ptr[dev] = p;
+  });
+  if (g_scratch_err[dev] != hipSuccess || !g_scratch_ptr[dev]) {
+    cradle_set_error("nb_logprob_fwd_bwd_static: hipGetSymbolAddress failed: %s", hipGetErrorString(g_scratch_err[dev]));
+    return CRADLE_ERR_HIP;
   }
   *out = g_scratch_ptr[dev];
   return CRADLE_OK;
@@ -448,6 +456,13 @@ int static_scratch(float** out) {
 extern "C" {
 
 int64_t cradle_nb_static_scratch_floats(void) { return kStaticScratchFloats; }
+
+// Resolves the scratch array's address on the current device now (the one call of cradle_nb_logprob_fwd_bwd_static's
+// path that is not capture-safe).  Optional otherwise: the first call on a device does it by itself.
+int cradle_nb_static_init(void) {
+  float* p = nullptr;
+  return static_scratch(&p);
+}
 
 int cradle_nb_logprob_fwd_bwd_static(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
                                      const float* X, int64_t ldx, const float* lib, const float* gene_consts,

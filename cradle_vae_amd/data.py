@@ -239,7 +239,7 @@ class DeviceBatchLoader:
         f32 = dict(device=dev, dtype=torch.float32)
         out = dict(X=torch.empty((N, G), **f32), D=torch.empty((N, T), **f32), qc=torch.empty((N, Q), **f32),
                    cfX=torch.empty((N, G), **f32), library_size=torch.empty((N,), **f32),
-                   treatments_present=torch.empty((1,), device=dev, dtype=torch.int32))
+                   treatments_present=torch.empty((2,), device=dev, dtype=torch.int32))  # [count, out-of-range flag]
         d = hip.BatchDesc()
         d.N, d.G, d.T, d.Q = N, G, T, Q
         d.x_type, d.cfx_type = self._COUNT_TYPES[t["X"].dtype], self._COUNT_TYPES[t["cfX"].dtype]
@@ -252,6 +252,7 @@ class DeviceBatchLoader:
         d.X_out, d.cfX_out, d.qc_out = out["X"].data_ptr(), out["cfX"].data_ptr(), out["qc"].data_ptr()
         d.lib_out, d.D_out, d.present_out = (out["library_size"].data_ptr(), out["D"].data_ptr(),
                                              out["treatments_present"].data_ptr())
+        d.rows, d.flags = t["X"].shape[0], out["treatments_present"].data_ptr() + 4
         hip.check(hip.load().cradle_gather_batch(ctypes.byref(d), hip.stream()), "cradle_gather_batch")
         return out
 
@@ -316,7 +317,10 @@ class DeviceBatchLoader:
             return batch
 
         def resolve(batch, pinned=None):
-            batch["treatments_present"] = int((batch["treatments_present"] if pinned is None else pinned)[0])
+            words = (batch["treatments_present"] if pinned is None else pinned).tolist()
+            if len(words) > 1 and words[1]:
+                raise IndexError("DeviceBatchLoader: a batch position lies outside the stored data set")
+            batch["treatments_present"] = int(words[0])
             return batch
 
         starts = list(range(0, stop, self.batch_size))
@@ -332,7 +336,7 @@ class DeviceBatchLoader:
             side.wait_stream(torch.cuda.current_stream(self.device))  # storage and pos_dev were made there
 
             if getattr(self, "_pinned", None) is None:  # two batches are in flight at most: a ring of four host words
-                self._pinned = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(4)]
+                self._pinned = [torch.empty(2, dtype=torch.int32, pin_memory=True) for _ in range(4)]
             ring = [0]
 
             def launch(s):
@@ -340,7 +344,10 @@ class DeviceBatchLoader:
                     b = gather(s)
                     pinned = self._pinned[ring[0] % 4]
                     ring[0] += 1
-                    pinned.copy_(b["treatments_present"], non_blocking=True)
+                    words = b["treatments_present"]
+                    pinned[:words.numel()].copy_(words, non_blocking=True)
+                    if words.numel() < 2:
+                        pinned[1] = 0
                     ev = torch.cuda.Event()
                     ev.record(side)
                 return b, ev, pinned

@@ -137,6 +137,43 @@ def dosage_matmul(plan: DosagePlan, table: torch.Tensor, n_particles: Optional[i
     return out[0] if squeeze else out
 
 
+class _DenseDosageMatmul(torch.autograd.Function):
+    """``matmul(D, table)`` as one fp32 MFMA GEMM per particle (NN layout; backward: D^T dout, TN layout) -- the dense
+    form, for a dosage matrix whose rows hold more non-zeros than the gather plans for.  D is data: no gradient."""
+
+    @staticmethod
+    def forward(ctx, D, table, P):
+        N, T = D.shape
+        L = table.shape[-1]
+        tab = table if table.dim() == 3 else table.unsqueeze(0)
+        out = torch.empty((P, N, L), device=D.device, dtype=torch.float32)
+        for p in range(P):
+            ops.gemm(ops.NN, D, tab[p if tab.shape[0] > 1 else 0], out[p])
+        ctx.save_for_backward(D)
+        ctx.shape = table.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (D,) = ctx.saved_tensors
+        P, N, L = dout.shape
+        dout = dout.contiguous()
+        d = torch.empty((P, D.shape[1], L), device=D.device, dtype=torch.float32)
+        for p in range(P):
+            ops.gemm(ops.TN, D, dout[p], d[p])
+        if len(ctx.shape) == 2:
+            d = d.sum(0)
+        elif ctx.shape[0] == 1 and P != 1:
+            d = d.sum(0, keepdim=True)
+        return None, d, None
+
+
+def dense_dosage_matmul(D: torch.Tensor, table: torch.Tensor, n_particles: Optional[int] = None) -> torch.Tensor:
+    """``torch.matmul(D, table)`` for D (N, T) and table (P, T, L) or (T, L) -> (P, N, L), on the HIP GEMM."""
+    P = n_particles if n_particles is not None else (table.shape[0] if table.dim() == 3 else 1)
+    return _DenseDosageMatmul.apply(D.contiguous().float(), table.contiguous(), P)
+
+
 class _OneHotLinear(torch.autograd.Function):
     """First layer of the embedding encoder on the input [mask | one_hot(t)] (correlated_normal_guide.py:
     147-153) without the one-hot: y[p, j, :] = LeakyReLU(mask[p, j] W[:, :L]^T + W[:, L + t_j] + b), the one-hot

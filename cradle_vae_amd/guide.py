@@ -211,7 +211,7 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
         """torch.matmul(D, table) for dosages D (N, T) and table (P, T, L) (correlated_normal_guide.py:186-188)
         through the <= max_dosages_per_cell non-zeros of each row."""
         if self.dense_dosage_matmul:  # the caller saw dosage_overflow: a cell with more dosages than planned for
-            return torch.matmul(D, table)
+            return F_hip.dense_dosage_matmul(D, table, P)
         plan = F_hip.DosagePlan(D, self.max_dosages_per_cell)
         self.dosage_overflow = plan.overflow if self.dosage_overflow is None else self.dosage_overflow | plan.overflow
         return F_hip.dosage_matmul(plan, table, P)

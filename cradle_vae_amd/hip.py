@@ -49,6 +49,7 @@ PROTOTYPES = {
          i32, i32, i32, c_stream],
     ),
     "cradle_nb_static_scratch_floats": (i64, []),
+    "cradle_nb_static_init": (i32, []),
     "cradle_nb_workspace_floats": (i64, [i32, i32, i32]),
     "cradle_nb_particle_split": (i32, [i32, i32]),
     "cradle_nb_tune": (None, [i32, i32]),
@@ -147,6 +148,7 @@ class BatchDesc(ctypes.Structure):
         [(k, i32) for k in ("N", "G", "T", "Q", "kmax", "x_type", "cfx_type")]
         + [(k, ctypes.c_void_p) for k in ("pos", "X", "cfX", "qc", "library_size", "d_idx", "d_val", "d_dense", "X_out",
                                           "cfX_out", "qc_out", "lib_out", "D_out", "present_out")]
+        + [("rows", i64), ("flags", ctypes.c_void_p)]
     )
 
 

@@ -178,7 +178,7 @@ class PerturbationPlatedELBOLossModule(torch.nn.Module):
         C = weights.shape[1]
         kmax = C if C <= 8 else self.guide.max_dosages_per_cell
         if getattr(self.guide, "dense_dosage_matmul", False):
-            return torch.matmul(weights, loss_term)
+            return F_hip.dense_dosage_matmul(weights, loss_term, loss_term.shape[0])
         # entries whose weight is zero (obs count 0 -> inf -> 0) drop out of the plan: they add nothing either way
         plan = F_hip.DosagePlan(weights, kmax)
         if C > 8:

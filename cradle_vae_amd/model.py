@@ -59,7 +59,7 @@ class cradle_vae_Model(torch.nn.Module):
         from . import functional as F_hip
 
         if self.dense_dosage_matmul:  # the caller saw dosage_overflow
-            return torch.matmul(D, table)
+            return F_hip.dense_dosage_matmul(D, table, P)
         plan = F_hip.DosagePlan(D, self.max_dosages_per_cell)
         self.dosage_overflow = plan.overflow if self.dosage_overflow is None else self.dosage_overflow | plan.overflow
         return F_hip.dosage_matmul(plan, table, P)

@@ -100,12 +100,15 @@ int cradle_nb_particle_split(int P, int N);
  * floats = 16 MiB, held by every GPU the library runs on until the process ends); a problem that needs more
  * (cradle_nb_workspace_floats(P, N, G) > that) is rejected with CRADLE_ERR_ARG.  Calls no hipMalloc/hipFree.
  * All calls on one GPU share the array: calls that overlap on one GPU (two streams, two threads) race.
- * Results are bit-identical to cradle_nb_logprob_fwd_bwd. */
+ * Results are bit-identical to cradle_nb_logprob_fwd_bwd.  The array's device address is looked up once per device
+ * (hipGetSymbolAddress, thread-safe) on the first call there -- that look-up is not legal under stream capture:
+ * call cradle_nb_static_init() once per device, with that device current, before capturing. */
 int cradle_nb_logprob_fwd_bwd_static(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
                                      const float* X, int64_t ldx, const float* library, const float* gene_consts,
                                      const float* grow, float* out, float* dlog_concentration, int accumulate,
                                      int P, int N, int G, cradle_stream_t stream);
 int64_t cradle_nb_static_scratch_floats(void);
+int cradle_nb_static_init(void);
 /* tuning hook for tools/bench_nb.py: threads per workgroup (256/512/1024), particle split; -1 = auto */
 void cradle_nb_tune(int threads, int particle_split);
 void cradle_nb_sample_tune(int threads); /* same for K9 below: 256 / 512 / 1024 threads per workgroup, -1 = automatic */
@@ -339,6 +342,9 @@ typedef struct cradle_batch_desc {
   float* lib_out;                /* (N) */
   float* D_out;                  /* (N, T) */
   int* present_out;              /* (1) or NULL */
+  int64_t rows;                  /* rows the stored tensors hold: pos[n] outside [0, rows) is never dereferenced (row 0
+                                    is gathered instead) and reported in *flags; 0 = unchecked */
+  int* flags;                    /* (1) or NULL: set to 0 by the call, bit 0 = a position was out of range */
 } cradle_batch_desc;
 int cradle_gather_batch(const cradle_batch_desc* desc, cradle_stream_t stream);
 

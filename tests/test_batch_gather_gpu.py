@@ -52,3 +52,29 @@ def test_hip_gather_equals_the_torch_loader(G, T, Q, xmax, cfmax, sparse, fracti
         for k in ("X", "cfX", "D", "qc", "library_size", "idx"):
             assert x[k].dtype == y[k].dtype and x[k].shape == y[k].shape and torch.equal(x[k], y[k]), k
     assert torch.equal(got[0]["X"], ds.X[got[0]["idx"].to(DEV)].float())
+
+
+def test_a_position_outside_the_stored_rows_is_reported_not_followed():
+    """cradle_batch_desc.rows: a stale or oversized index into the stored data set (a loader reused after its data set
+    shrank, a corrupted permutation) must not be dereferenced on the device: the gather reads row 0 in its place, raises
+    the flag, and the loader turns that into an IndexError when it hands the batch over."""
+    import ctypes
+
+    from cradle_vae_amd import hip
+    from cradle_vae_amd.data import DeviceBatchLoader
+
+    ds = _dataset(40, 32, 6, 1, 50, 5, seed=1)
+    loader = DeviceBatchLoader(ds, 16, device=DEV, prefetch=False)
+    good = torch.tensor([3, 5, 39], device=DEV)
+    out = loader._gather_hip(good)
+    torch.cuda.synchronize()
+    assert out["treatments_present"].tolist()[1] == 0 and torch.equal(out["X"], ds.X[good].float())
+    bad = torch.tensor([3, 40, -1, 7], device=DEV)  # 40 and -1 do not exist
+    out = loader._gather_hip(bad)
+    torch.cuda.synchronize()
+    assert out["treatments_present"].tolist()[1] == 1
+    assert torch.equal(out["X"][[0, 3]], ds.X[torch.tensor([3, 7], device=DEV)].float())
+    assert torch.equal(out["X"][1], ds.X[0].float()) and torch.equal(out["X"][2], ds.X[0].float())
+    loader._indices = lambda: (torch.tensor([1, 2, 99]), torch.tensor([1, 2, 99]))
+    with pytest.raises(IndexError, match="outside the stored data set"):
+        list(loader)

@@ -83,3 +83,27 @@ def test_guide_samples_match_reference(name):
         r = ref[k].double()
         err = float((s[k].cpu().double() - r).abs().max()) / max(float(r.abs().max()), 1e-6)
         assert err <= 2e-5, (k, err)
+
+
+def test_dense_dosage_product_runs_on_the_hip_gemm():
+    """matmul(D, table) for a dosage matrix denser than the gather plans for (the fallback of guide / model / loss module /
+    ATE when a cell carries more than max_dosages_per_cell dosages): one HIP GEMM per particle forward, D^T dout backward
+    -- against torch in fp64, real-valued dosages, a width that is not a multiple of 4, shared and per-particle tables."""
+    from cradle_vae_amd import functional as F_hip
+
+    g = torch.Generator().manual_seed(4)
+    N, T, L, P = 37, 53, 18, 3
+    D = (torch.rand(N, T, generator=g) < 0.4).float() * torch.rand(N, T, generator=g)
+    for shape in ((P, T, L), (1, T, L), (T, L)):
+        table = torch.randn(*shape, generator=g)
+        t_dev = table.to(DEV).requires_grad_(True)
+        out = F_hip.dense_dosage_matmul(D.to(DEV), t_dev, P)
+        w = torch.randn(P, N, L, generator=g)
+        (out * w.to(DEV)).sum().backward()
+        t64 = table.double().requires_grad_(True)
+        ref = torch.matmul(D.double(), t64 if t64.dim() == 3 else t64.unsqueeze(0)).expand(P, N, L)
+        (ref * w.double()).sum().backward()
+        assert out.shape == (P, N, L)
+        assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-5 * float(ref.abs().max())
+        assert t_dev.grad.shape == table.shape
+        assert float((t_dev.grad.cpu().double() - t64.grad).abs().max()) <= 1e-5 * float(t64.grad.abs().max())

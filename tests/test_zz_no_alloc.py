@@ -43,6 +43,7 @@ def test_static_scratch_entry_equals_workspace_entry_on_two_calls():
 
     lib_ = hip.load()
     assert lib_.cradle_nb_static_scratch_floats() == 4 << 20
+    assert lib_.cradle_nb_static_init() == 0  # the address look-up, made eagerly (what a capturing caller does first)
     for (P, N, G, seed) in ((5, 96, 1200, 1), (3, 40, 300, 2)):  # the second call is the smaller one
         logits, X, lib, log_c, grow = _inputs(P, N, G, seed)
         consts = ops.nb_gene_consts(log_c)
