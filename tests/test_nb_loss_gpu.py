@@ -7,7 +7,7 @@ from oracle import cradle_oracle as co
 pytestmark = pytest.mark.gpu
 
 
-def _case(P, N, G, seed, count_scale=1.0, big_counts=False):
+def _case(P, N, G, seed, count_scale=1.0, big_counts=False, tiny_c=False):
     g = torch.Generator().manual_seed(seed)
     logits = 2.0 * torch.randn(P * N, G, generator=g, dtype=torch.float64)
     lam = torch.exp(-1.0 + 1.5 * torch.randn(G, generator=g, dtype=torch.float64)) * count_scale
@@ -16,6 +16,9 @@ def _case(P, N, G, seed, count_scale=1.0, big_counts=False):
         X[:, : G // 8] = torch.poisson(3000.0 * torch.rand(N, G // 8, generator=g, dtype=torch.float64), generator=g)
     lib = X.sum(1) + 1.0
     log_c = 1.2 * torch.randn(G, generator=g, dtype=torch.float64)
+    if tiny_c:  # concentrations far below a millionth of the mean: rate = c / (mu + 1e-4) sits on its clamp (mlp.py:163)
+        log_c[::7] = -30.0
+        log_c[3::11] = -18.0
     grow = torch.randn(P * N, generator=g, dtype=torch.float64)
     return logits.float().double(), X, lib, log_c.float().double(), grow.float().double()
 
@@ -46,6 +49,7 @@ def _oracle(logits, X, lib, log_c, grow, P):
         (5, 64, 301, {}),   # gene counts that are not a multiple of 4: rows are run as the next multiple,
         (2, 9, 1202, {}),   # the tail is masked in the kernel
         (3, 17, 5003, dict(big_counts=True)),
+        (4, 24, 1000, dict(tiny_c=True)),  # the rate clamp active on real genes (K1's single-reciprocal form, nb_math.h)
     ],
 )
 def test_nb_logprob_matches_oracle(P, N, G, kw):
