@@ -473,6 +473,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = one_step(i)
+    enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3  # host time to issue a step (no wait on the device)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -532,6 +533,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "host_enqueue_ms_per_step": enqueue_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -155,21 +155,18 @@ int finalize_loss(const float* recon, const float* wrec, const float* ltz, const
                   const float* SE, const float* Sq, const float* cw, const float* cwq, float beta, int P, int N, int T,
                   int Q, const int* flags, float* out, hipStream_t stream);
 
-// ---- qc_chain.hip : q(qc_E) (Q rows through an MLP) as single-workgroup launches
-bool qc_chain_supported(int Q, int L, int Hm, int He, int Hd, int PP);
-// every layer, the heads, the draws + log-ratio sums S, qsum, vq = qc_E . Wqc^T (PP*Q, He), wq = qsum . Wbad^T (P, Hd)
+// ---- qc_chain.hip : q(qc_E) (Q <= 2 rows through an MLP) as single-workgroup launches
+bool qc_chain_supported(int Q, int L, int Hm, int PP);
+// every layer, the heads, the draws qc_E + their log-ratio sums S, qsum (what qce_fwd + the GEMM chain before it make)
 int qc_chain_fwd(const cradle_mlp_ptrs& m, float* const* y, float* const* r, float* heads, const float* eps, const float* ploc,
-                 const float* pscale, float* qcE, float* sd, float* S, float* qsum, const float* Wqc, int64_t ldwqc, float* vq,
-                 const float* Wbad, int64_t ldwbad, float* wq, int Q, int L, int Hm, int He, int Hd, int PP, int P,
+                 const float* pscale, float* qcE, float* sd, float* S, float* qsum, int Q, int L, int Hm, int PP, int P,
                  hipStream_t stream);
-// d qc_E = dvq . Wqc (+ dwq . Wbad for the main pass), the Gaussian head's backward, the data-gradient chain (da[k] left
-// in HBM), every bias and weight gradient of the qc encoder.  dWqc / dWbad: NULL (the caller makes them) or where
-// dvq^T qc_E / dwq^T qsum go.
+// the Gaussian head's backward from dq_enc (PP*Q, L) / dq_dec (P, L), the data-gradient chain (da[k] left in HBM), every
+// bias gradient; then every weight gradient of the encoder in one more launch
 int qc_chain_bwd(const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, float* const* y, float* const* r, float* const* da,
                  const float* heads, float* dheads, const float* eps, const float* ploc, const float* pscale, const float* qcE,
-                 const float* sd, const float* coefQ, const float* dvq, const float* dwq, const float* qsum, const float* Wqc,
-                 int64_t ldwqc, float* dWqc, const float* Wbad, int64_t ldwbad, float* dWbad, int Q, int L, int Hm, int He,
-                 int Hd, int PP, int P, hipStream_t stream);
+                 const float* sd, const float* coefQ, const float* dq_enc, const float* dq_dec, int Q, int L, int Hm, int PP,
+                 int P, hipStream_t stream);
 
 // ---- adam.hip
 int adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

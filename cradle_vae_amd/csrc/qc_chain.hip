@@ -25,85 +25,158 @@ namespace cradle {
 namespace {
 
 constexpr int kQcThreads = 1024;
-constexpr int kQcRows = 8;  // rows a matrix-vector pass carries at once
+constexpr int kQcFwdThreads = 512;  // the forward chain keeps 13 weight rows per wave in flight: 256 VGPRs per thread
+constexpr int kQcRows = 8;       // rows a matrix-vector pass carries at once
+constexpr int kQcPart = 16384;   // floats of LDS the slice partials of wg_rows_matT may take
 
-// out(r, h) = sum_k W[h * ldw + k] * x[r * ldx + k] for r < R <= kQcRows, h < H: a wave per output feature h, lanes
-// along k.  x in LDS.  emit(h, r, value) is called by lane 0 of the wave that owns h.
-template <typename F>
-__device__ __forceinline__ void wg_rows_dot(const float* __restrict__ W, int64_t ldw, int H, int K, const float* x, int ldx,
-                                            int R, F&& emit) {
+// A single workgroup reading a few hundred KB of weights is bound by how many loads it keeps in flight, not by
+// arithmetic: both products below issue the loads of several weight rows before they touch any of them.
+
+// out(r, h) = sum_k W[h * ldw + k] * x[r * ldx + k] for r < R <= RMAX, h < H: a wave per output feature h, lanes
+// along k, HB features per wave in flight at once (HB * RMAX <= 16).  x in LDS.  The HB * RMAX partial sums of a
+// wave meet through LDS (red: kQcRedFloats per wave; 78 cross-lane shuffles per batch otherwise -- measured: they, not
+// the loads, set the kernel's time): four lanes per sum add sixteen lanes' partials each, two shuffles finish it.
+// emit(h, r, value) is called by one lane per result.  Every thread of the workgroup must call (barriers inside).
+constexpr int kQcRedFloats = 16 * 65;
+template <int RMAX, int HB, typename F>
+__device__ __forceinline__ void wg_rows_dot_t(const float* __restrict__ W, int64_t ldw, int H, int K, const float* x, int ldx,
+                                              int R, float* red, F&& emit) {
+  static_assert(HB * RMAX <= 16, "four lanes per partial sum");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const bool vec = (K & 3) == 0 && (ldw & 3) == 0 && ((uintptr_t)W & 15) == 0 && (ldx & 3) == 0;
-  for (int h = wave; h < H; h += nw) {
-    float acc[kQcRows];
-#pragma unroll
-    for (int r = 0; r < kQcRows; ++r) acc[r] = 0.f;
-    const float* w = W + (int64_t)h * ldw;
+  const bool vec = (K & 3) == 0 && (ldw & 3) == 0 && ((uintptr_t)W & 15) == 0 && (ldx & 3) == 0 && K <= 512;
+  float* my = red + wave * kQcRedFloats;
+  const int K4 = K >> 2;
+  for (int hb = 0; hb < H; hb += nw * HB) {  // (the same trip count for every wave)
+    const int h0 = hb + wave;
+    float acc[HB][RMAX];
     if (vec) {
-      for (int k4 = lane; k4 < (K >> 2); k4 += 64) {
-        const float4 wv = reinterpret_cast<const float4*>(w)[k4];
+      float4 w0[HB], w1[HB];  // k4 = lane and lane + 64 of HB rows: all loads issued before the first use
 #pragma unroll
-        for (int r = 0; r < kQcRows; ++r)
-          if (r < R) {
-            const float4 xv = reinterpret_cast<const float4*>(x + r * ldx)[k4];
-            acc[r] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
-          }
+      for (int i = 0; i < HB; ++i) {
+        const int h = h0 + i * nw;
+        const float4* wr = reinterpret_cast<const float4*>(W + (int64_t)(h < H ? h : 0) * ldw);
+        w0[i] = lane < K4 ? wr[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        w1[i] = lane + 64 < K4 ? wr[lane + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-    } else {
-      for (int k = lane; k < K; k += 64) {
-        const float wv = w[k];
 #pragma unroll
-        for (int r = 0; r < kQcRows; ++r)
-          if (r < R) acc[r] = fmaf(wv, x[r * ldx + k], acc[r]);
+      for (int r = 0; r < RMAX; ++r) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (r < R ? r : 0) * ldx);
+        const float4 x0 = lane < K4 ? xr[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 x1 = lane + 64 < K4 ? xr[lane + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < HB; ++i)
+          acc[i][r] = ((w0[i].x * x0.x + w0[i].y * x0.y) + (w0[i].z * x0.z + w0[i].w * x0.w)) +
+                      ((w1[i].x * x1.x + w1[i].y * x1.y) + (w1[i].z * x1.z + w1[i].w * x1.w));
+      }
+    } else {  // any K, any alignment
+#pragma unroll
+      for (int i = 0; i < HB; ++i) {
+        const int h = h0 + i * nw;
+        const float* w = W + (int64_t)(h < H ? h : 0) * ldw;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) acc[i][r] = 0.f;
+        for (int k = lane; k < K; k += 64) {
+          const float wv = w[k];
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) acc[i][r] = fmaf(wv, x[(r < R ? r : 0) * ldx + k], acc[i][r]);
+        }
       }
     }
 #pragma unroll
-    for (int r = 0; r < kQcRows; ++r)
-      if (r < R) {
-        const float v = wave_sum(acc[r]);
-        if (lane == 0) emit(h, r, v);
+    for (int i = 0; i < HB; ++i)
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) my[(i * RMAX + r) * 65 + lane] = acc[i][r];
+    __syncthreads();
+    {
+      const int item = lane >> 2, q = lane & 3;
+      float sacc = 0.f;
+      if (item < HB * RMAX) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sacc += my[item * 65 + q * 16 + t];
       }
+      sacc += __shfl_xor(sacc, 1, 64);
+      sacc += __shfl_xor(sacc, 2, 64);
+      const int i = item / RMAX, r = item % RMAX, h = h0 + i * nw;
+      if (q == 0 && item < HB * RMAX && h < H && r < R) emit(h, r, sacc);
+    }
+    __syncthreads();
   }
+}
+template <typename F>
+__device__ __forceinline__ void wg_rows_dot(const float* __restrict__ W, int64_t ldw, int H, int K, const float* x, int ldx,
+                                            int R, float* red, F&& emit) {
+  if (R == 1) wg_rows_dot_t<1, 13>(W, ldw, H, K, x, ldx, R, red, emit);
+  else wg_rows_dot_t<2, 8>(W, ldw, H, K, x, ldx, R, red, emit);  // R == 2 (qc_chain_supported)
 }
 
 // out(r, n) = sum_h a[r * lda + h] * W[h * ldw + n] for r < R <= kQcRows, n < Nout: threads along n (coalesced rows of
-// W), the h range cut into slices that meet in LDS.  a in LDS; part: LDS scratch of slices * R * Nout floats.
-// emit(r, n, value) is called once per (r, n) by one thread.
-template <typename F>
-__device__ __forceinline__ void wg_rows_matT(const float* __restrict__ W, int64_t ldw, int Hin, int Nout, const float* a,
-                                             int lda, int R, float* part, F&& emit) {
-  const int cols = Nout;
-  int slices = blockDim.x / cols;
+// W, four columns per thread where the layout allows), the h range cut into slices that meet in LDS, eight rows of W
+// in flight per thread.  a in LDS; part: LDS scratch of kQcPart floats (slices * R * Nout of them are used;
+// Nout * R <= kQcPart).  emit(r, n, value) is called once per (r, n) by one thread.
+template <int V, typename F>
+__device__ __forceinline__ void wg_rows_matT_t(const float* __restrict__ W, int64_t ldw, int Hin, int Nout, const float* a,
+                                               int lda, int R, float* part, F&& emit) {
+  const int cols = Nout, colsv = Nout / V;  // V == 4: Nout % 4 == 0 (checked by the caller)
+  int slices = min(min((int)blockDim.x / colsv, 32), kQcPart / (R * cols));
   if (slices < 1) slices = 1;
-  if (slices > 16) slices = 16;
   const int per = (Hin + slices - 1) / slices;
-  for (int base = 0; base < cols; base += blockDim.x / slices) {  // (one pass when Nout * slices <= threads)
-    const int width = min((int)(blockDim.x / slices), cols - base);
-    const int sl = threadIdx.x / width, n = base + threadIdx.x % width;
+  const int lanes = (int)blockDim.x / slices;  // column groups handled per pass
+  for (int base = 0; base < colsv; base += lanes) {
+    const int width = min(lanes, colsv - base);
+    const int sl = threadIdx.x / width, nv = base + threadIdx.x % width;
     if (sl < slices) {
-      float acc[kQcRows];
+      float acc[kQcRows][V];
 #pragma unroll
-      for (int r = 0; r < kQcRows; ++r) acc[r] = 0.f;
+      for (int r = 0; r < kQcRows; ++r)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[r][e] = 0.f;
       const int h1 = min(Hin, (sl + 1) * per);
-      for (int h = sl * per; h < h1; ++h) {
-        const float wv = W[(int64_t)h * ldw + n];
+      for (int h = sl * per; h < h1; h += 8) {
+        float wv[8][V];
 #pragma unroll
-        for (int r = 0; r < kQcRows; ++r)
-          if (r < R) acc[r] = fmaf(a[r * lda + h], wv, acc[r]);
+        for (int i = 0; i < 8; ++i) {  // eight independent loads before any use
+          const float* wp = W + (int64_t)min(h + i, h1 - 1) * ldw + nv * V;
+          if constexpr (V == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(wp);
+            wv[i][0] = t.x; wv[i][1] = t.y; wv[i][2] = t.z; wv[i][3] = t.w;
+          } else {
+            wv[i][0] = wp[0];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (h + i < h1) {
+#pragma unroll
+            for (int r = 0; r < kQcRows; ++r)
+              if (r < R) {
+                const float av = a[r * lda + h + i];
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[r][e] = fmaf(av, wv[i][e], acc[r][e]);
+              }
+          }
       }
 #pragma unroll
       for (int r = 0; r < kQcRows; ++r)
-        if (r < R) part[(sl * kQcRows + r) * cols + n] = acc[r];
+        if (r < R) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) part[(sl * R + r) * cols + nv * V + e] = acc[r][e];
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < R * width; i += blockDim.x) {
-      const int r = i / width, nn = base + i % width;
+    for (int i = threadIdx.x; i < R * width * V; i += blockDim.x) {
+      const int r = i / (width * V), nn = base * V + i % (width * V);
       float v = 0.f;
-      for (int s = 0; s < slices; ++s) v += part[(s * kQcRows + r) * cols + nn];  // fixed order
+      for (int s = 0; s < slices; ++s) v += part[(s * R + r) * cols + nn];  // fixed order
       emit(r, nn, v);
     }
     __syncthreads();
   }
+}
+template <typename F>
+__device__ __forceinline__ void wg_rows_matT(const float* __restrict__ W, int64_t ldw, int Hin, int Nout, const float* a,
+                                             int lda, int R, float* part, F&& emit) {
+  if ((Nout & 3) == 0 && (ldw & 3) == 0 && ((uintptr_t)W & 15) == 0) wg_rows_matT_t<4>(W, ldw, Hin, Nout, a, lda, R, part, emit);
+  else wg_rows_matT_t<1>(W, ldw, Hin, Nout, a, lda, R, part, emit);
 }
 
 struct QcFwdArgs {
@@ -113,42 +186,41 @@ struct QcFwdArgs {
   float* heads;                 // (Q, 2L)
   const float *eps, *ploc, *pscale;
   float *qcE, *sd, *S, *qsum;
-  const float* Wqc;  // (He, ldwqc): qc block of the basal encoder's first layer
-  int64_t ldwqc;
-  float* vq;         // (PP*Q, He)
-  const float* Wbad;  // (Hd, ldwbad): qc block of the decoder's first layer
-  int64_t ldwbad;
-  float* wq;          // (P, Hd)
-  int Q, L, Hm, He, Hd, PP, P;
+  int Q, L, Hm, PP, P;
 };
 
 __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : kLeakySlope * v; }
 
-__global__ __launch_bounds__(kQcThreads) void qc_chain_fwd_kernel(const QcFwdArgs a) {
+__global__ __launch_bounds__(kQcFwdThreads) void qc_chain_fwd_kernel(const QcFwdArgs a) {
   extern __shared__ float sm[];
   const int Q = a.Q, L = a.L, Hm = a.Hm, n = a.m.n_layers;
   const int Kmax = max(max(L, Hm), 4);
   const int ld = (Kmax + 3) & ~3;
   float* xa = sm;                      // (Q, ld) current layer input
-  float* xb = xa + kQcRows * ld;       // (Q, ld) current layer output
-  float* hd = xb + kQcRows * ld;       // (Q, 2L) heads
-  float* qe = hd + kQcRows * 2 * L;    // (PP*Q, ldq) draws, then (P, ldq) their sums over q
+  float* xb = xa + Q * ld;             // (Q, ld) current layer output
+  float* hd = xb + Q * ld;             // (Q, 2L) heads
+  float* qe = hd + Q * 2 * L;          // (PP*Q, ldq) draws, then (P, ldq) their sums over q
   const int ldq = (L + 3) & ~3;
   float* qs = qe + (size_t)a.PP * Q * ldq;  // (P, ldq)
-
+  float* bs = qs + (size_t)a.P * ldq;       // (n, Hm) layer biases, then (2L) the heads': no global load where a result
+                                            // is delivered (one lane per output: such a load would be a latency each)
+  float* red = bs + n * Hm + 2 * L;         // (waves, kQcRedFloats)
+  for (int k = 0; k < n; ++k)
+    for (int i = threadIdx.x; i < Hm; i += blockDim.x) bs[k * Hm + i] = a.m.b[k][i];
+  for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) bs[n * Hm + i] = a.m.b_head[i];
   for (int i = threadIdx.x; i < Q * ld; i += blockDim.x) xa[i] = (i % ld) < L ? 1.0f : 0.f;  // the input: ones(Q, L)
   __syncthreads();
   // layer 0: y0 = LeakyReLU(x W0^T + b0)
-  wg_rows_dot(a.m.W[0], L, Hm, L, xa, ld, Q, [&](int h, int r, float v) {
-    const float y = leaky(v + a.m.b[0][h]);
+  wg_rows_dot(a.m.W[0], L, Hm, L, xa, ld, Q, red, [&](int h, int r, float v) {
+    const float y = leaky(v + bs[h]);
     xb[r * ld + h] = y;
     a.y[0][r * Hm + h] = y;
   });
   __syncthreads();
   for (int k = 1; k < n; ++k) {  // y_k = LeakyReLU(y_{k-1} W_k^T + b_k) + y_{k-1}
     float* t = xa; xa = xb; xb = t;
-    wg_rows_dot(a.m.W[k], Hm, Hm, Hm, xa, ld, Q, [&](int h, int r, float v) {
-      const float act = leaky(v + a.m.b[k][h]);
+    wg_rows_dot(a.m.W[k], Hm, Hm, Hm, xa, ld, Q, red, [&](int h, int r, float v) {
+      const float act = leaky(v + bs[k * Hm + h]);
       a.r[k][r * Hm + h] = act;
       const float y = act + xa[r * ld + h];
       xb[r * ld + h] = y;
@@ -156,8 +228,8 @@ __global__ __launch_bounds__(kQcThreads) void qc_chain_fwd_kernel(const QcFwdArg
     });
     __syncthreads();
   }
-  wg_rows_dot(a.m.W_head, Hm, 2 * L, Hm, xb, ld, Q, [&](int o, int r, float v) {
-    const float h = v + a.m.b_head[o];
+  wg_rows_dot(a.m.W_head, Hm, 2 * L, Hm, xb, ld, Q, red, [&](int o, int r, float v) {
+    const float h = v + bs[n * Hm + o];
     hd[r * 2 * L + o] = h;
     a.heads[r * 2 * L + o] = h;
   });
@@ -192,14 +264,6 @@ __global__ __launch_bounds__(kQcThreads) void qc_chain_fwd_kernel(const QcFwdArg
     qs[p * ldq + l] = s;
     a.qsum[i] = s;
   }
-  __syncthreads();
-  // vq = qc_E . Wqc^T (PP*Q rows), wq = qsum . Wbad^T (P rows), kQcRows rows at a time
-  for (int r0 = 0; r0 < a.PP * Q; r0 += kQcRows)
-    wg_rows_dot(a.Wqc, a.ldwqc, a.He, L, qe + r0 * ldq, ldq, min(kQcRows, a.PP * Q - r0),
-                [&](int h, int r, float v) { a.vq[(int64_t)(r0 + r) * a.He + h] = v; });
-  for (int r0 = 0; r0 < a.P; r0 += kQcRows)
-    wg_rows_dot(a.Wbad, a.ldwbad, a.Hd, L, qs + r0 * ldq, ldq, min(kQcRows, a.P - r0),
-                [&](int h, int r, float v) { a.wq[(int64_t)(r0 + r) * a.Hd + h] = v; });
 }
 
 struct QcBwdArgs {
@@ -210,42 +274,21 @@ struct QcBwdArgs {
   const float* heads;
   float* dheads;  // (Q, 2L)
   const float *eps, *ploc, *pscale, *qcE, *sd, *coefQ;
-  const float* dvq;   // (PP*Q, He) gradient of qc_E . Wqc^T
-  const float* dwq;   // (P, Hd) gradient of the decoder's bad-variant shift
-  const float* Wqc;
-  int64_t ldwqc;
-  const float* Wbad;
-  int64_t ldwbad;
-  int Q, L, Hm, He, Hd, PP, P;
+  const float* dq_enc;  // (PP*Q, L) d qc_E through the basal encoder's first layer
+  const float* dq_dec;  // (P, L) d qc_E through the decoder's bad-variant shift (the same for every q)
+  int Q, L, Hm, PP, P;
 };
 
 __global__ __launch_bounds__(kQcThreads) void qc_chain_bwd_kernel(const QcBwdArgs a) {
   extern __shared__ float sm[];
   const int Q = a.Q, L = a.L, Hm = a.Hm, n = a.m.n_layers;
-  const int Kmax = max(max(max(2 * L, Hm), max(a.He, a.Hd)), 4);
-  float* in = sm;                                   // (kQcRows, Kmax) rows fed to a product
-  float* G = in + kQcRows * Kmax;                   // (Q, Hm) running data gradient
-  float* dav = G + kQcRows * Hm;                    // (Q, Hm) pre-activation gradient of the current layer
-  float* dq = dav + kQcRows * Hm;                   // (PP*Q, L) d qc_E
-  float* part = dq + (size_t)a.PP * Q * L;          // 16 * kQcRows * max(Hm, L) slice partials
-  float* dh = part + 16 * kQcRows * max(Hm, 2 * L);  // (Q, 2L)
+  const int Kmax = max(max(2 * L, Hm), 4);
+  float* in = sm;                 // (Q, Kmax) rows fed to a product
+  float* G = in + Q * Kmax;       // (Q, Hm) running data gradient
+  float* dav = G + Q * Hm;        // (Q, Hm) pre-activation gradient of the current layer
+  float* part = dav + Q * Hm;     // kQcPart floats of slice partials
+  float* dh = part + kQcPart;     // (Q, 2L)
 
-  // d qc_E from the encoder: dq[row] = dvq[row] . Wqc  (rows of qc_E . Wqc^T), kQcRows rows at a time
-  for (int r0 = 0; r0 < a.PP * Q; r0 += kQcRows) {
-    const int R = min(kQcRows, a.PP * Q - r0);
-    for (int i = threadIdx.x; i < R * a.He; i += blockDim.x) in[(i / a.He) * Kmax + i % a.He] = a.dvq[(int64_t)r0 * a.He + i];
-    __syncthreads();
-    wg_rows_matT(a.Wqc, a.ldwqc, a.He, L, in, Kmax, R, part, [&](int r, int l, float v) { dq[(r0 + r) * L + l] = v; });
-  }
-  // ... and from the decoder's shift (the same for every q of a particle of the main pass)
-  for (int r0 = 0; r0 < a.P; r0 += kQcRows) {
-    const int R = min(kQcRows, a.P - r0);
-    for (int i = threadIdx.x; i < R * a.Hd; i += blockDim.x) in[(i / a.Hd) * Kmax + i % a.Hd] = a.dwq[(int64_t)r0 * a.Hd + i];
-    __syncthreads();
-    wg_rows_matT(a.Wbad, a.ldwbad, a.Hd, L, in, Kmax, R, part, [&](int r, int l, float v) {
-      for (int q = 0; q < Q; ++q) dq[((r0 + r) * Q + q) * L + l] += v;
-    });
-  }
   // the Gaussian head: particles summed in order -> dheads (Q, 2L)
   for (int i = threadIdx.x; i < Q * L; i += blockDim.x) {
     const int q = i / L, l = i % L;
@@ -255,9 +298,10 @@ __global__ __launch_bounds__(kQcThreads) void qc_chain_bwd_kernel(const QcBwdArg
     for (int pp = 0; pp < a.PP; ++pp) {
       const int64_t j = ((int64_t)pp * Q + q) * L + l;
       const float s = a.qcE[j], ep = a.eps[j];
-      float ds = dq[j];
+      float ds = a.dq_enc[j];
       float coef = 0.f;
       if (pp < a.P) {
+        ds += a.dq_dec[pp * L + l];
         coef = cq;
         ds += coef * (-(s - pl) / (ps * ps));
       }
@@ -336,51 +380,53 @@ __global__ __launch_bounds__(256) void qc_chain_wgrad_kernel(const OuterJobs job
 
 }  // namespace
 
-bool qc_chain_supported(int Q, int L, int Hm, int He, int Hd, int PP) {
-  // one workgroup, everything it carries between layers in LDS
-  const int Kmax = std::max(std::max(std::max(2 * L, Hm), std::max(He, Hd)), 4);
-  const size_t bwd = ((size_t)kQcRows * Kmax + 2 * (size_t)kQcRows * Hm + (size_t)PP * Q * L +
-                      16 * (size_t)kQcRows * std::max(Hm, 2 * L) + (size_t)kQcRows * 2 * L) * 4;
-  return Q >= 1 && Q <= kQcRows && bwd <= 150 * 1024;
+static size_t qc_fwd_lds(int Q, int L, int Hm, int PP, int P, int n_layers) {
+  const int ld = (std::max(std::max(L, Hm), 4) + 3) & ~3, ldq = (L + 3) & ~3;
+  return ((size_t)2 * Q * ld + (size_t)Q * 2 * L + (size_t)PP * Q * ldq + (size_t)P * ldq + (size_t)n_layers * Hm +
+          2 * (size_t)L + (size_t)(kQcFwdThreads / 64) * kQcRedFloats) * 4;
+}
+static size_t qc_bwd_lds(int Q, int L, int Hm) {
+  const int Kmax = std::max(std::max(2 * L, Hm), 4);
+  return ((size_t)Q * Kmax + 2 * (size_t)Q * Hm + kQcPart + (size_t)Q * 2 * L) * 4;
+}
+
+bool qc_chain_supported(int Q, int L, int Hm, int PP) {
+  // one workgroup, everything it carries between layers in LDS; a product's rows x columns within the partials' budget
+  return Q >= 1 && Q <= 2 && (int64_t)Q * std::max(Hm, 2 * L) <= kQcPart &&
+         qc_fwd_lds(Q, L, Hm, PP, PP / 2, CRADLE_MAX_LAYERS) <= 150 * 1024 && qc_bwd_lds(Q, L, Hm) <= 150 * 1024;
 }
 
 int qc_chain_fwd(const cradle_mlp_ptrs& m, float* const* y, float* const* r, float* heads, const float* eps, const float* ploc,
-                 const float* pscale, float* qcE, float* sd, float* S, float* qsum, const float* Wqc, int64_t ldwqc, float* vq,
-                 const float* Wbad, int64_t ldwbad, float* wq, int Q, int L, int Hm, int He, int Hd, int PP, int P,
+                 const float* pscale, float* qcE, float* sd, float* S, float* qsum, int Q, int L, int Hm, int PP, int P,
                  hipStream_t stream) {
   QcFwdArgs a = {};
   a.m = m;
   for (int k = 0; k < m.n_layers; ++k) { a.y[k] = y[k]; a.r[k] = r[k]; }
   a.heads = heads; a.eps = eps; a.ploc = ploc; a.pscale = pscale; a.qcE = qcE; a.sd = sd; a.S = S; a.qsum = qsum;
-  a.Wqc = Wqc; a.ldwqc = ldwqc; a.vq = vq; a.Wbad = Wbad; a.ldwbad = ldwbad; a.wq = wq;
-  a.Q = Q; a.L = L; a.Hm = Hm; a.He = He; a.Hd = Hd; a.PP = PP; a.P = P;
-  const int ld = (std::max(std::max(L, Hm), 4) + 3) & ~3, ldq = (L + 3) & ~3;
-  const size_t lds = ((size_t)2 * kQcRows * ld + (size_t)kQcRows * 2 * L + (size_t)PP * Q * ldq + (size_t)P * ldq) * 4;
+  a.Q = Q; a.L = L; a.Hm = Hm; a.PP = PP; a.P = P;
+  const size_t lds = qc_fwd_lds(Q, L, Hm, PP, P, m.n_layers);
   if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)qc_chain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds) != hipSuccess) {
     cradle_set_error("qc_chain_fwd: cannot reserve %zu bytes of LDS", lds);
     return CRADLE_ERR_HIP;
   }
-  hipLaunchKernelGGL(qc_chain_fwd_kernel, dim3(1), dim3(kQcThreads), lds, stream, a);
+  hipLaunchKernelGGL(qc_chain_fwd_kernel, dim3(1), dim3(kQcFwdThreads), lds, stream, a);
   CRADLE_CHECK_LAUNCH("qc_chain_fwd_kernel");
   return CRADLE_OK;
 }
 
 int qc_chain_bwd(const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, float* const* y, float* const* r, float* const* da,
                  const float* heads, float* dheads, const float* eps, const float* ploc, const float* pscale, const float* qcE,
-                 const float* sd, const float* coefQ, const float* dvq, const float* dwq, const float* qsum, const float* Wqc,
-                 int64_t ldwqc, float* dWqc, const float* Wbad, int64_t ldwbad, float* dWbad, int Q, int L, int Hm, int He,
-                 int Hd, int PP, int P, hipStream_t stream) {
+                 const float* sd, const float* coefQ, const float* dq_enc, const float* dq_dec, int Q, int L, int Hm, int PP,
+                 int P, hipStream_t stream) {
   QcBwdArgs a = {};
   a.m = m; a.g = g;
   const int n = m.n_layers;
   for (int k = 0; k < n; ++k) { a.y[k] = y[k]; a.r[k] = r[k]; a.da[k] = da[k]; }
   a.heads = heads; a.dheads = dheads; a.eps = eps; a.ploc = ploc; a.pscale = pscale; a.qcE = qcE; a.sd = sd; a.coefQ = coefQ;
-  a.dvq = dvq; a.dwq = dwq; a.Wqc = Wqc; a.ldwqc = ldwqc; a.Wbad = Wbad; a.ldwbad = ldwbad;
-  a.Q = Q; a.L = L; a.Hm = Hm; a.He = He; a.Hd = Hd; a.PP = PP; a.P = P;
-  const int Kmax = std::max(std::max(std::max(2 * L, Hm), std::max(He, Hd)), 4);
-  const size_t lds = ((size_t)kQcRows * Kmax + 2 * (size_t)kQcRows * Hm + (size_t)PP * Q * L +
-                      16 * (size_t)kQcRows * std::max(Hm, 2 * L) + (size_t)kQcRows * 2 * L) * 4;
+  a.dq_enc = dq_enc; a.dq_dec = dq_dec;
+  a.Q = Q; a.L = L; a.Hm = Hm; a.PP = PP; a.P = P;
+  const size_t lds = qc_bwd_lds(Q, L, Hm);
   if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)qc_chain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds) != hipSuccess) {
     cradle_set_error("qc_chain_bwd: cannot reserve %zu bytes of LDS", lds);
@@ -388,7 +434,7 @@ int qc_chain_bwd(const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, float* cons
   }
   hipLaunchKernelGGL(qc_chain_bwd_kernel, dim3(1), dim3(kQcThreads), lds, stream, a);
   CRADLE_CHECK_LAUNCH("qc_chain_bwd_kernel");
-  // every weight gradient of the chain in one launch
+  // every weight gradient of the encoder in one launch
   OuterJobs jobs = {};
   auto add = [&](const float* aa, int64_t lda, const float* bb, int64_t ldb, float* out, int64_t ldo, int R, int O, int H) {
     jobs.j[jobs.n++] = OuterJob{aa, bb, out, lda, ldb, ldo, R, O, H};
@@ -396,11 +442,15 @@ int qc_chain_bwd(const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, float* cons
   add(dheads, 2 * L, y[n - 1], Hm, g.W_head, Hm, Q, 2 * L, Hm);                // dW_head = dheads^T y_last
   for (int k = n - 1; k >= 1; --k) add(da[k], Hm, y[k - 1], Hm, g.W[k], Hm, Q, Hm, Hm);  // dW_k = da_k^T y_{k-1}
   add(da[0], Hm, nullptr, 0, g.W[0], L, Q, Hm, L);                             // dW_0 = da_0^T ones(Q, L)
-  if (dWqc) add(dvq, He, qcE, L, dWqc, ldwqc, PP * Q, He, L);                  // dWqc = dvq^T qc_E
-  if (dWbad) add(dwq, Hd, qsum, L, dWbad, ldwbad, P, Hd, L);                   // dWbad = dwq^T qsum
   hipLaunchKernelGGL(qc_chain_wgrad_kernel, dim3(64, jobs.n), dim3(256), 0, stream, jobs);
   CRADLE_CHECK_LAUNCH("qc_chain_wgrad_kernel");
   return CRADLE_OK;
 }
 
 }  // namespace cradle
+
+extern "C" int cradle_qc_chain_supported(int Q, int L, int Hm, int He, int Hd, int P) {
+  (void)He;
+  (void)Hd;
+  return cradle::qc_chain_supported(Q, L, Hm, 2 * P) ? 1 : 0;
+}

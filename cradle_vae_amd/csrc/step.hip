@@ -520,7 +520,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   const float* nz_E = own_noise ? w.eps_E : d.eps_E;
   const float* nz_q = own_noise ? w.eps_qc_E : d.eps_qc_E;
   const float* nz_z = own_noise ? w.eps_z : d.eps_z;
-  const bool qc_fused = qc_chain_supported(Q, L, Hm, He, Hd, PP) && !(sched_flags() & 4);
+  const bool qc_fused = qc_chain_supported(Q, L, Hm, PP) && !(sched_flags() & 4);
 #define STEP(call)        \
   do {                    \
     rc = (call);          \
@@ -578,9 +578,8 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   // shipped configuration: 1); else, or with CRADLE_SCHED bit 2 set, the chain of GEMM launches it replaces
   hipEvent_t ev_vq = nullptr;
   if (qc_fused) {
-    STEP(qc_chain_fwd(d.qce, w.yq, w.rq, w.headsq, nz_q, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.Sq, w.qsum,
-                      Wenc0 + G + L, ldenc, w.vq, Wd0 + 2 * L, 3 * L, w.wq, Q, L, Hm, He, Hd, PP, P, s2));
-    ev_vq = c.record(2);
+    STEP(qc_chain_fwd(d.qce, w.yq, w.rq, w.headsq, nz_q, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.Sq, w.qsum, Q, L, Hm,
+                      PP, P, s2));
   } else {
     hipLaunchKernelGGL(fill_kernel, dim3((Q * L + 255) / 256), dim3(256), 0, s2, w.ones_q, (int64_t)Q * L, 1.0f);
     {  // constant input ones(Q, L)
@@ -592,10 +591,10 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
     head_fwd(c, d.qce, Q, Hm, 2 * L, w.yq[d.qce.n_layers - 1], w.headsq, 2);
     if (c.rc) return c.rc;
     STEP(qce_fwd(w.headsq, nz_q, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.Sq, w.qsum, PP, P, Q, L, s2));
-    c.gemm(GEMM_NT, gp(w.qcE, L, Wenc0 + G + L, ldenc, w.vq, He, PP * Q, He, L), 2);  // qc_E Wqc^T
-    ev_vq = c.record(2);
-    c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L), 2);        // bad-variant shift per particle
   }
+  c.gemm(GEMM_NT, gp(w.qcE, L, Wenc0 + G + L, ldenc, w.vq, He, PP * Q, He, L), 2);  // qc_E Wqc^T
+  ev_vq = c.record(2);
+  c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L), 2);        // bad-variant shift per particle
   STEP(nb_gene_consts_padded(d.log_concentration, w.gene_consts, G, Gp, s2));
   hipEvent_t ev_s2 = c.record(2);
 
@@ -704,7 +703,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   STEP(weighted_rowgroup_sum(da0d, w.cp.live, P, N, Hd, w.dwq, s2));
   c.gemm(GEMM_TN, gp(w.dwq, Hd, w.qsum, L, d.d_dec.W[0] + 2 * L, 3 * L, Hd, L, P), 2);  // dW0[:, 2L:]
   mark_all(c, d.ev_bucket[1]);  // every decoder gradient has been enqueued
-  if (!qc_fused) c.gemm(GEMM_NN, gp(w.dwq, Hd, Wd0 + 2 * L, 3 * L, w.dq_dec, L, P, L, Hd), 2);  // d qsum
+  c.gemm(GEMM_NN, gp(w.dwq, Hd, Wd0 + 2 * L, 3 * L, w.dq_dec, L, P, L, Hd), 2);         // d qsum
   c.gemm(GEMM_NN, gp(da0d, Hd, Wd0, 3 * L, w.dzoff, 2 * L, PN, 2 * L, Hd));             // [dz | doff]
   if (c.rc) return c.rc;
 
@@ -734,12 +733,11 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   if (c.rc) return c.rc;
 
   // q(qc_E): whole backward on stream 2 (tiny, off the critical path; dwq and dvq were made there)
+  c.gemm(GEMM_NN, gp(w.dvq, He, Wenc0 + G + L, ldenc, w.dq_enc, L, PP * Q, L, He), 2);    // d qc_E via encoder
   if (qc_fused) {
     STEP(qc_chain_bwd(d.qce, d.d_qce, w.yq, w.rq, w.daq, w.headsq, w.dheadsq, nz_q, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE,
-                      w.sdq, w.cp.coefQ, w.dvq, w.dwq, w.qsum, Wenc0 + G + L, ldenc, nullptr, Wd0 + 2 * L, 3 * L, nullptr, Q,
-                      L, Hm, He, Hd, PP, P, s2));
+                      w.sdq, w.cp.coefQ, w.dq_enc, w.dq_dec, Q, L, Hm, PP, P, s2));
   } else {
-    c.gemm(GEMM_NN, gp(w.dvq, He, Wenc0 + G + L, ldenc, w.dq_enc, L, PP * Q, L, He), 2);    // d qc_E via encoder
     STEP(qce_bwd(w.headsq, nz_q, d.p_qc_E_loc, d.p_qc_E_scale, w.qcE, w.sdq, w.dq_enc, w.dq_dec, w.cp.coefQ,
                  w.dheadsq, PP, P, Q, L, s2));
     const float* da0q = head_trunk_bwd(c, d.qce, d.d_qce, Q, Hm, 2 * L, w.dheadsq, w.yq, w.rq, w.Gq, w.daq, 2, 2, 2);

@@ -276,6 +276,9 @@ int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only 
  * "eps_qc_E" (2P*Q*L), "eps_z" (P*N*L).  Returns the element count, or -1. */
 int64_t cradle_elbo_step_intermediate(const cradle_step_desc* desc, const char* name, const float** ptr);
 int cradle_elbo_step(const cradle_step_desc* desc, cradle_stream_t stream);
+/* 1 when cradle_elbo_step runs q(qc_E) (n_qc rows through the qc encoder, correlated_normal_guide.py:162-166) as its
+ * single-workgroup chain kernels (three launches) at these sizes, 0 when as a chain of GEMM launches (same results) */
+int cradle_qc_chain_supported(int Q, int L, int Hm, int He, int Hd, int P);
 /* measuring hook for tools/phase_sweep.py (never used on the product path): the step returns after its k-th
  * internal checkpoint with all streams joined (its outputs are then incomplete); 0 = run everything */
 void cradle_step_debug_stop_after(int checkpoint);

@@ -118,6 +118,8 @@ def compare_with_oracle(shape, kmax, seed, compact, precisions=("f32", "bf16x3")
             loss, metrics, grads = run_fused(lm, case)
         d = lm._fused.desc
         assert (d.N * d.kmax < d.T) == compact  # Replogle runs the compact treatment axis
+        # ... and q(qc_E) as its single-workgroup chain (qc_chain.hip) at every shipped size, not as ~35 GEMM launches
+        assert lm._fused.lib.cradle_qc_chain_supported(d.Q, d.L, d.Hm, d.He, d.Hd, d.P) == 1
         assert d.precision == {"f32": 0, "bf16x3": 1, "bf16": 2}[precision]
 
         rtol = 1e-4
@@ -196,3 +198,19 @@ def test_fused_equals_modular_at_the_scale_up_shape():
         assert err < 2e-3, (k, err)
         l2 = float((g_f[k] - ref).norm()) / max(float(ref.norm()), 1e-12)
         assert l2 < 1e-4, (k, l2)
+
+
+def test_gemm_chain_form_of_the_qc_encoder_matches_oracle():
+    """q(qc_E) runs as three single-workgroup launches where the shape allows (csrc/qc_chain.hip: every test above)
+    and as a chain of GEMM launches otherwise (n_qc > 2, or an MLP too wide for LDS).  The second form at the Adamson
+    shape, forced with CRADLE_SCHED=4 -- the library reads that variable once, hence the child process."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import tests.test_fused_fullsize_gpu as t; from cradle_vae_amd import synthetic as syn; "
+            "print(t.compare_with_oracle(syn.SHAPES['adamson'], 2, 18, compact=False, precisions=('f32',), param_seed=24))")
+    env = dict(os.environ, CRADLE_SCHED="4")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
