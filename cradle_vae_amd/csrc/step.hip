@@ -377,7 +377,11 @@ const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_p
       c.wait(wq, ev_dout);
     }
     c.gemm(GEMM_TN, p, wq);
-    mark_all(c, ev_head_done);  // the output layer's gradients have been enqueued
+    // the output layer's gradients have been enqueued, all of them on `wq`: the event goes there
+    if (ev_head_done && !c.rc && hipEventRecord((hipEvent_t)ev_head_done, c.st[wq]) != hipSuccess) {
+      cradle_set_error("elbo_step: bucket event record failed");
+      c.rc = CRADLE_ERR_HIP;
+    }
   }
   int side = wq2;  // the output layer's product went to wq
   auto wgrad = [&](int k, int stream) {  // dW_k = da_k^T y_{k-1}
