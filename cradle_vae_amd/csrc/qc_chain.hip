@@ -1,19 +1,22 @@
-// q(qc_E) of the ELBO step as three launches instead of ~35.
+// q(qc_E) of the ELBO step: the Q-row work of its encoder as three launches instead of seventeen.
 //
 // Reference: the qc encoder of cradle_vae_CorrelatedNormalGuide.forward (cradle_vae/models/cradle_vae/guides/
-// correlated_normal_guide.py:162-166: GaussianLikelihoodResidualMLP on the constant input ones(Q, L), mlp.py:111-142),
-// the products matmul(qc, qc_E) / matmul(1 - qc, qc_E) that enter the basal encoder's first layer (:189-197, here the
-// vectors qc_E . Wqc^T) and the bad-variant shift ones(N, Q) @ qc_E of the decoder input (model.py:122).
+// correlated_normal_guide.py:162-166: GaussianLikelihoodResidualMLP on the constant input ones(Q, L), mlp.py:111-142)
+// and the reparameterised draws qc_E with their log-ratio sums (loss_modules.py:153-177).
 //
 // The encoder runs on Q rows (Q = 1 in every shipped configuration): every layer is a matrix-vector product that cannot
-// occupy more than a few CUs, and as GEMM launches the chain was ten kernels forward and about twenty-five backward on
-// a side stream -- launch floors and first-load latencies, nothing else.  Here:
-//   qc_chain_fwd   one workgroup: all layers, the heads, the reparameterised draw + log-ratio sums, qc_E . Wqc^T and
-//                  the decoder shift, activations kept in LDS between layers;
-//   qc_chain_bwd   one workgroup: d qc_E from the encoder and decoder sides, the Gaussian head's backward, the
-//                  data-gradient chain through the layers (pre-activation gradients left in HBM), bias gradients;
-//   qc_chain_wgrad many workgroups: every weight gradient of the chain, each a sum of <= 2P*Q outer products.
-// Latency-bound by design (a few hundred KB of weights through one CU per layer); off the step's critical path.
+// occupy more than a few CUs, and as GEMM launches the chain was six kernels forward and eleven backward on a side
+// stream -- launch floors and first-load latencies, nothing else.  Here:
+//   qc_chain_fwd   one workgroup: all layers, the heads, the 2P*Q draws + log-ratio sums and the per-particle sum over
+//                  q, activations kept in LDS between layers;
+//   qc_chain_bwd   one workgroup: the Gaussian head's backward from d qc_E, the data-gradient chain through the layers
+//                  (pre-activation gradients left in HBM), bias gradients;
+//   qc_chain_wgrad many workgroups: every weight gradient of the chain, each a sum of Q outer products.
+// The products over the 2P*Q particle rows (qc_E . Wqc^T into the basal encoder's first layer, correlated_normal_guide.py:
+// 189-197; the decoder's bad-variant shift, model.py:122; their data gradients) stay GEMM launches in step.hip: in here
+// they were most of the time (first version: 370 / 140 us forward / backward; now 69 / 81).
+// Latency-bound by design (one CU streams the MLP's weights at ~45 GB/s); off the step's critical path.  Q <= 2; wider
+// qc or an MLP beyond the LDS budget takes the GEMM chain (qc_chain_supported).
 #include "common.h"
 #include "gauss_math.h"
 #include "kernels.h"
@@ -26,7 +29,7 @@ namespace {
 
 constexpr int kQcThreads = 1024;
 constexpr int kQcFwdThreads = 512;  // the forward chain keeps 13 weight rows per wave in flight: 256 VGPRs per thread
-constexpr int kQcRows = 8;       // rows a matrix-vector pass carries at once
+constexpr int kQcRows = 2;       // rows a matrix-vector pass carries at once (Q <= 2)
 constexpr int kQcPart = 16384;   // floats of LDS the slice partials of wg_rows_matT may take
 
 // A single workgroup reading a few hundred KB of weights is bound by how many loads it keeps in flight, not by
@@ -199,10 +202,9 @@ __global__ __launch_bounds__(kQcFwdThreads) void qc_chain_fwd_kernel(const QcFwd
   float* xa = sm;                      // (Q, ld) current layer input
   float* xb = xa + Q * ld;             // (Q, ld) current layer output
   float* hd = xb + Q * ld;             // (Q, 2L) heads
-  float* qe = hd + Q * 2 * L;          // (PP*Q, ldq) draws, then (P, ldq) their sums over q
+  float* qe = hd + Q * 2 * L;          // (PP*Q, ldq) draws
   const int ldq = (L + 3) & ~3;
-  float* qs = qe + (size_t)a.PP * Q * ldq;  // (P, ldq)
-  float* bs = qs + (size_t)a.P * ldq;       // (n, Hm) layer biases, then (2L) the heads': no global load where a result
+  float* bs = qe + (size_t)a.PP * Q * ldq;  // (n, Hm) layer biases, then (2L) the heads': no global load where a result
                                             // is delivered (one lane per output: such a load would be a latency each)
   float* red = bs + n * Hm + 2 * L;         // (waves, kQcRedFloats)
   for (int k = 0; k < n; ++k)
@@ -261,7 +263,6 @@ __global__ __launch_bounds__(kQcFwdThreads) void qc_chain_fwd_kernel(const QcFwd
     const int p = i / L, l = i % L;
     float s = 0.f;
     for (int q = 0; q < Q; ++q) s += qe[(p * Q + q) * ldq + l];
-    qs[p * ldq + l] = s;
     a.qsum[i] = s;
   }
 }
@@ -380,9 +381,9 @@ __global__ __launch_bounds__(256) void qc_chain_wgrad_kernel(const OuterJobs job
 
 }  // namespace
 
-static size_t qc_fwd_lds(int Q, int L, int Hm, int PP, int P, int n_layers) {
+static size_t qc_fwd_lds(int Q, int L, int Hm, int PP, int n_layers) {
   const int ld = (std::max(std::max(L, Hm), 4) + 3) & ~3, ldq = (L + 3) & ~3;
-  return ((size_t)2 * Q * ld + (size_t)Q * 2 * L + (size_t)PP * Q * ldq + (size_t)P * ldq + (size_t)n_layers * Hm +
+  return ((size_t)2 * Q * ld + (size_t)Q * 2 * L + (size_t)PP * Q * ldq + (size_t)n_layers * Hm +
           2 * (size_t)L + (size_t)(kQcFwdThreads / 64) * kQcRedFloats) * 4;
 }
 static size_t qc_bwd_lds(int Q, int L, int Hm) {
@@ -393,7 +394,7 @@ static size_t qc_bwd_lds(int Q, int L, int Hm) {
 bool qc_chain_supported(int Q, int L, int Hm, int PP) {
   // one workgroup, everything it carries between layers in LDS; a product's rows x columns within the partials' budget
   return Q >= 1 && Q <= 2 && (int64_t)Q * std::max(Hm, 2 * L) <= kQcPart &&
-         qc_fwd_lds(Q, L, Hm, PP, PP / 2, CRADLE_MAX_LAYERS) <= 150 * 1024 && qc_bwd_lds(Q, L, Hm) <= 150 * 1024;
+         qc_fwd_lds(Q, L, Hm, PP, CRADLE_MAX_LAYERS) <= 150 * 1024 && qc_bwd_lds(Q, L, Hm) <= 150 * 1024;
 }
 
 int qc_chain_fwd(const cradle_mlp_ptrs& m, float* const* y, float* const* r, float* heads, const float* eps, const float* ploc,
@@ -404,7 +405,7 @@ int qc_chain_fwd(const cradle_mlp_ptrs& m, float* const* y, float* const* r, flo
   for (int k = 0; k < m.n_layers; ++k) { a.y[k] = y[k]; a.r[k] = r[k]; }
   a.heads = heads; a.eps = eps; a.ploc = ploc; a.pscale = pscale; a.qcE = qcE; a.sd = sd; a.S = S; a.qsum = qsum;
   a.Q = Q; a.L = L; a.Hm = Hm; a.PP = PP; a.P = P;
-  const size_t lds = qc_fwd_lds(Q, L, Hm, PP, P, m.n_layers);
+  const size_t lds = qc_fwd_lds(Q, L, Hm, PP, m.n_layers);
   if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)qc_chain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds) != hipSuccess) {
     cradle_set_error("qc_chain_fwd: cannot reserve %zu bytes of LDS", lds);
@@ -449,8 +450,6 @@ int qc_chain_bwd(const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, float* cons
 
 }  // namespace cradle
 
-extern "C" int cradle_qc_chain_supported(int Q, int L, int Hm, int He, int Hd, int P) {
-  (void)He;
-  (void)Hd;
+extern "C" int cradle_qc_chain_supported(int Q, int L, int Hm, int P) {
   return cradle::qc_chain_supported(Q, L, Hm, 2 * P) ? 1 : 0;
 }

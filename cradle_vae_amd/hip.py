@@ -66,7 +66,7 @@ PROTOTYPES = {
     "cradle_elbo_step_workspace_bytes": (i64, [ctypes.c_void_p]),
     "cradle_elbo_step": (i32, [ctypes.c_void_p, c_stream]),
     "cradle_step_debug_stop_after": (None, [i32]),
-    "cradle_qc_chain_supported": (i32, [i32, i32, i32, i32, i32, i32]),
+    "cradle_qc_chain_supported": (i32, [i32, i32, i32, i32]),
     "cradle_elbo_step_intermediate": (i64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
     "cradle_adam_step": (
         i32,

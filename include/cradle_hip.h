@@ -277,8 +277,9 @@ int64_t cradle_elbo_step_workspace_bytes(const cradle_step_desc* desc); /* only 
 int64_t cradle_elbo_step_intermediate(const cradle_step_desc* desc, const char* name, const float** ptr);
 int cradle_elbo_step(const cradle_step_desc* desc, cradle_stream_t stream);
 /* 1 when cradle_elbo_step runs q(qc_E) (n_qc rows through the qc encoder, correlated_normal_guide.py:162-166) as its
- * single-workgroup chain kernels (three launches) at these sizes, 0 when as a chain of GEMM launches (same results) */
-int cradle_qc_chain_supported(int Q, int L, int Hm, int He, int Hd, int P);
+ * single-workgroup chain kernels (three launches) at these sizes -- n_qc Q <= 2, latent width L, the qc encoder's hidden
+ * width Hm, P particles --, 0 when as a chain of GEMM launches (same results) */
+int cradle_qc_chain_supported(int Q, int L, int Hm, int P);
 /* measuring hook for tools/phase_sweep.py (never used on the product path): the step returns after its k-th
  * internal checkpoint with all streams joined (its outputs are then incomplete); 0 = run everything */
 void cradle_step_debug_stop_after(int checkpoint);

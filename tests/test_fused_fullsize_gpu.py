@@ -118,8 +118,8 @@ def compare_with_oracle(shape, kmax, seed, compact, precisions=("f32", "bf16x3")
             loss, metrics, grads = run_fused(lm, case)
         d = lm._fused.desc
         assert (d.N * d.kmax < d.T) == compact  # Replogle runs the compact treatment axis
-        # ... and q(qc_E) as its single-workgroup chain (qc_chain.hip) at every shipped size, not as ~35 GEMM launches
-        assert lm._fused.lib.cradle_qc_chain_supported(d.Q, d.L, d.Hm, d.He, d.Hd, d.P) == 1
+        # ... and q(qc_E) as its single-workgroup chain (qc_chain.hip) at every shipped size, not as a chain of GEMM launches
+        assert lm._fused.lib.cradle_qc_chain_supported(d.Q, d.L, d.Hm, d.P) == 1
         assert d.precision == {"f32": 0, "bf16x3": 1, "bf16": 2}[precision]
 
         rtol = 1e-4
