@@ -84,6 +84,17 @@ def k1_pmc_traffic(G, N, P):
     return d.get("traffic_bytes")
 
 
+def k9_pmc_traffic(G, C, P):
+    """HBM bytes per K9 launch (sampler + partial sums) from the committed rocprofv3 --pmc passes
+    (profiles/k9_pmc.json, tools/pmc_round.sh); None if no pass was made at this launch shape."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "k9_pmc.json")) as f:
+            d = json.load(f)
+    except OSError:
+        return None
+    return d.get("traffic_bytes") if d.get("shape") == {"G": G, "C": C, "P": P} else None
+
+
 def measured_copy_gbs(device, mbytes=512, reps=10):
     """Achievable HBM bandwidth on this device as a plain device-to-device copy sees it (read + write
     bytes over time): context for the K1 fraction, which is quoted against the 8 TB/s peak."""
@@ -292,7 +303,7 @@ def ate_bench(lm, shape, device, args):
         full = [t for t in k9 if t >= 0.5 * max(k9)]  # (the last chunk of 2500 = 19 x 128 + 68 is shorter)
         t_k9 = sum(full) / len(full)
         res["roofline"] = {"bound": "hbm", "achieved": alg / t_k9 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": alg / t_k9 / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "frac": alg / t_k9 / 1e9 / HBM_PEAK_GBS, "traffic": k9_pmc_traffic(G, slab, ATE_CHUNK),
                            "kernel": "nb_sample_accumulate_kernel + partial_sums_kernel (K9: softmax, Gamma-Poisson draw, "
                                      "perturb-seq transform, particle sum)",
                            "launch_us": t_k9 * 1e6, "launches_timed": len(full), "algorithmic_bytes_per_launch": alg,
