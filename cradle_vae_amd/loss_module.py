@@ -90,10 +90,17 @@ class PerturbationPlatedELBOLossModule(torch.nn.Module):
             return False
         if not next(self.parameters()).is_cuda and self.step == "auto":
             return False  # CPU tensors: the module-level path raises inside the first kernel wrapper
-        ok = step_mod.supports(self)
-        if self.step == "fused" and not ok:
-            raise NotImplementedError("this configuration is not supported by the fused HIP step")
-        return ok
+        why = step_mod.unsupported_reason(self)
+        if self.step == "fused" and why:
+            raise NotImplementedError(f"this configuration is not supported by the fused HIP step: {why}")
+        if why and not getattr(self, "_warned_modular", False):
+            import warnings
+
+            self._warned_modular = True  # once per module: step = 'auto' never changes paths without saying so
+            warnings.warn(f"loss_module.step='auto': the fused HIP step does not run this configuration ({why}); using "
+                          "the modular HIP path -- the same kernels composed in Python with autograd, about ten times "
+                          "slower per step (DESIGN 2)")
+        return why is None
 
     def _fused_step(self):
         if self._fused is None or self._fused.kmax != int(self.max_dosages_per_cell):

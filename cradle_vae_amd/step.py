@@ -23,21 +23,28 @@ OUT_KEYS = ["loss", "loss_term_reconstruction", "loss_term_mask", "loss_term_E",
             "cf_KLdivergence"]
 
 
-def supports(lm) -> bool:
+def unsupported_reason(lm):
+    """None when the fused step runs this loss module, else what keeps it on the modular path (one sentence)."""
     from .guide import cradle_vae_CorrelatedNormalGuide
     from .mlp import LibraryGammaPoissonSharedConcentrationResidualMLP
     from .model import cradle_vae_Model
 
     m, g = lm.model, lm.guide
     if not isinstance(m, cradle_vae_Model) or not isinstance(g, cradle_vae_CorrelatedNormalGuide):
-        return False
-    if m.sum_mode or not isinstance(m.decoder, LibraryGammaPoissonSharedConcentrationResidualMLP):
-        return False
+        return f"model / guide classes {type(m).__name__} / {type(g).__name__} are not the ones it implements"
+    if m.sum_mode:
+        return "sum_mode=True"
+    if not isinstance(m.decoder, LibraryGammaPoissonSharedConcentrationResidualMLP):
+        return f"likelihood {getattr(m, 'likelihood_key', '?')!r} (it implements library_nb)"
     if m.n_phenos < 4:
-        return False
+        return f"n_phenos={m.n_phenos} < 4"
     if not next(lm.parameters()).is_cuda:
         raise hip.CradleHipError("cradle_vae_amd runs on the GPU only: move the module to a cuda device (no CPU path)")
-    return True
+    return None
+
+
+def supports(lm) -> bool:
+    return unsupported_reason(lm) is None
 
 
 class ParamArena:

@@ -76,3 +76,30 @@ def test_widest_supported_gene_axis_and_one_beyond():
                              qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"], library_size=batch["library_size"],
                              n_particles=shape.n_particles)
     torch.cuda.synchronize()
+
+
+def test_three_genes_take_the_modular_path_and_say_so():
+    """n_phenos < 4 is the one shape the fused step does not run (K1's rows are 16-byte vectors): step = 'auto' takes
+    the modular HIP path -- same kernels, autograd between them, ~10x slower -- and warns once, with the reason;
+    step = 'fused' raises with the same reason."""
+    import warnings
+
+    import bench
+    from cradle_vae_amd import synthetic as syn
+
+    shape = dataclasses.replace(syn.SHAPES["tiny"], name="tiny_g3", n_phenos=3)
+    lm, batch = bench.build(shape, DEV, seed=3)
+    lm.step = "auto"
+    kw = dict(X=batch["X"], D=batch["D"], D_obs_counts=batch["D_obs_counts"], qc=batch["qc"],
+              qc_obs_counts=batch["qc_obs_counts"], cfX=batch["cfX"],
+              condition_values={"library_size": batch["library_size"]}, n_particles=shape.n_particles)
+    with pytest.warns(UserWarning, match="n_phenos=3 < 4"):
+        loss, _ = lm.loss(**kw)
+    assert bool(torch.isfinite(loss))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # ... once per module
+        loss2, _ = lm.loss(**kw)
+    assert bool(torch.isfinite(loss2))
+    lm.step = "fused"
+    with pytest.raises(NotImplementedError, match="n_phenos=3 < 4"):
+        lm.loss(**kw)
