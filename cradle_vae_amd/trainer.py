@@ -222,7 +222,7 @@ class TrainStep:
         """Raises -- on EVERY rank, in the same call -- if any rank's step rejected its input since the last look (a cell
         with more than kmax dosages, qc outside {0,1}): such a step's update was skipped on all ranks.  One rank: the
         fused step's own check.  Collective for N > 1: every rank must call it at the same point (the step does so
-        on its first call and every 256th; trainer.fit at the end of every epoch and after validation)."""
+        on its first training step and every 256th; trainer.fit at the end of every epoch and after validation)."""
         if self.fused is None:
             return
         if self.world_size == 1:
@@ -247,7 +247,10 @@ class TrainStep:
     def __call__(self, batch: Dict[str, torch.Tensor], n_particles: int) -> torch.Tensor:
         if self.fused is not None:
             loss = self._fused_call(batch, n_particles)
-            if self.world_size > 1 and self.fused.check_due:
+            # collective: every rank must get here in the same call, so the schedule hangs on the count of TRAINING steps
+            # (equal on all ranks: the loaders cut equal shards) and not on the fused step's own call counter, which
+            # also counts a rank's validation batches (shards of a validation set can differ by one batch)
+            if self.world_size > 1 and (self.step_count == 1 or self.step_count % 256 == 0):
                 self.check_flags()
             return loss
         noise, cf_noise = self.draw_noise(n_particles, batch["X"].shape[0])
@@ -327,10 +330,12 @@ def fit(module, train_loader, val_loader=None, *, max_epochs: int = 1, max_steps
                 vtot = v if vtot is None else vtot + v
                 vcnt += batch["X"].shape[0]
             stepper.check_flags()  # forward-only steps reject inputs too
-            if vtot is not None:
-                t = torch.stack([vtot, torch.tensor(float(vcnt), device=vtot.device)])
+            if vtot is not None or world > 1:  # (a rank whose validation shard is empty still takes part in the sum)
+                t = torch.stack([vtot if vtot is not None else torch.zeros((), device=stepper.device),
+                                 torch.tensor(float(vcnt), device=stepper.device)])
                 parallel.allreduce_sum_(t, world)
-                record["val/loss"] = float(t[0] / t[1])
+                if float(t[1]) > 0:
+                    record["val/loss"] = float(t[0] / t[1])
         history.append(record)
         try:
             for cb in callbacks:
