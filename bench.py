@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from cradle_vae_amd.env import set_hw_queues_for_multi_gpu  # noqa: E402  (imports nothing but os)
 
-set_hw_queues_for_multi_gpu()  # an existing GPU_MAX_HW_QUEUES is respected, CRADLE_HW_QUEUES must lie in 1..32
+set_hw_queues_for_multi_gpu()  # CRADLE_HW_QUEUES=<1..32>|keep chooses; an existing setting below 6 is raised, with a notice
 
 import torch  # noqa: E402
 
