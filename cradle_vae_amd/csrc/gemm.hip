@@ -120,6 +120,15 @@ struct TileLoader {
   }
 };
 
+// problem b of a batched launch (GemmParams::batch): its operands, result and split-K partials
+__device__ __forceinline__ void batch_offsets(GemmParams& p, int b) {
+  p.A += (int64_t)b * p.bs_a;
+  p.B += (int64_t)b * p.bs_b;
+  p.C += (int64_t)b * p.bs_c;
+  if (p.extra_col) p.extra_col += (int64_t)b * p.bs_x;
+  if (p.partial) p.partial += (int64_t)b * p.splitk * p.slab;
+}
+
 // WK = 2: eight waves per workgroup; waves 4-7 take the second half of every K step of the same
 // 2x2 arrangement of 32x32 tiles, so each SIMD holds two waves whose LDS round trips
 // (write -> barrier -> fragment read) hide behind the other's MFMA chain; their partial
@@ -128,8 +137,10 @@ struct TileLoader {
 // 64x64 tiles to occupy the chip: with WK = 4 the four waves of a workgroup split every K step
 // four ways, so a 1050 x 400 x 400 product runs on ~430 workgroups x 4 SIMDs instead of 119.
 template <bool A_KMAJOR, bool B_KMAJOR, int TM, int TN, int BK, int D, int WK, bool VEC, int WS = 2>
-__global__ __launch_bounds__(64 * WS * WS * WK) void gemm_f32_kernel(const GemmParams p) {
+__global__ __launch_bounds__(64 * WS * WS * WK) void gemm_f32_kernel(const GemmParams p_in) {
   constexpr int BM = WS * TM * 32, BN = WS * TN * 32, NT = 64 * WS * WS * WK;
+  GemmParams p = p_in;
+  if (p_in.batch > 1) batch_offsets(p, blockIdx.y);
   using LA = TileLoader<A_KMAJOR, BM, BK, NT>;
   using LB = TileLoader<B_KMAJOR, BN, BK, NT>;
   constexpr int STAGE = LA::lds_floats() + LB::lds_floats();
@@ -285,7 +296,9 @@ __global__ __launch_bounds__(64 * WS * WS * WK) void gemm_f32_kernel(const GemmP
 // Sums the split-K partial tiles (fixed order: deterministic) and applies the epilogue.  Every
 // thread takes four consecutive elements of the flattened (M, Np) result: the slabs are padded to
 // a multiple of four floats, so the partials stream in as 16-byte loads whatever Np is.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p_in) {
+  GemmParams p = p_in;
+  if (p_in.batch > 1) batch_offsets(p, blockIdx.y);
   const int Np = p.N + (p.extra_col ? 1 : 0);
   const int64_t total = (int64_t)p.M * Np;
   const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -376,20 +389,22 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
   if (tiles(1, 1) <= 600 && flops <= 5e9) { ws = 1; bk = 32; wk = 4; }
   if (g_tune_tm > 0) { ws = g_tune_ws; tm = g_tune_tm; tn = g_tune_tn; bk = g_tune_bk; depth = g_tune_depth; wk = g_tune_wk; }
   const int64_t ntiles = tiles_ws(ws, tm, tn);
+  const int batch = max(1, p.batch);
+  const int64_t wgs = ntiles * batch;  // workgroups in flight before any K split
   const int k_tiles = (p.K + bk - 1) / bk;
   int splitk = 1;
-  if (workspace && ws == 1 && ntiles < 768) {
-    splitk = (int)min((int64_t)8, (768 + ntiles - 1) / ntiles);
+  if (workspace && ws == 1 && wgs < 768) {
+    splitk = (int)min((int64_t)8, (768 + wgs - 1) / wgs);
     splitk = max(1, min(splitk, k_tiles / 8));
-  } else if (workspace && ws == 2 && ntiles < 2048) {
-    splitk = (int)min((int64_t)16, (2048 + ntiles - 1) / ntiles);
+  } else if (workspace && ws == 2 && wgs < 2048) {
+    splitk = (int)min((int64_t)16, (2048 + wgs - 1) / wgs);
     splitk = max(1, min(splitk, k_tiles / 16));
   }
   if (p.splitk_hint > 0) splitk = min(p.splitk_hint, max(1, k_tiles / 2));
   if (g_tune_splitk > 0) splitk = g_tune_splitk;
   if (!workspace || (uintptr_t)workspace % 16 != 0) splitk = 1;
   p.slab = ((int64_t)p.M * Np + 3) & ~int64_t(3);
-  while (splitk > 1 && (int64_t)splitk * p.slab > workspace_floats) --splitk;
+  while (splitk > 1 && (int64_t)splitk * batch * p.slab > workspace_floats) --splitk;
   p.k_tiles_per_split = (k_tiles + splitk - 1) / splitk;
   splitk = (k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
   p.splitk = splitk;
@@ -411,7 +426,12 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
   if (layout == 0) aligned = aligned && p.K % 4 == 0;
   else if (layout == 1) aligned = aligned && p.K % 4 == 0 && row_ok(p.N, p.ldb);
   else aligned = aligned && row_ok(p.M, p.lda) && row_ok(p.N, p.ldb);
-  if (p.precision >= 1 && aligned && flops >= 1.0e9) {
+  if (batch > 1) {
+    CRADLE_CHECK_ARG(!p.bias && !p.rowbias && !p.rowscale && !p.act && !p.res && !p.dact_src && !p.C2 && p.beta == 0.f &&
+                         batch <= 65535,
+                     "gemm: a batched launch takes plain products only (batch %d)", batch);
+  }
+  if (p.precision >= 1 && aligned && flops >= 1.0e9 && batch == 1) {
     // split-bf16 kernels: 128 x 128 tiles, 64 in a dimension that pads less that way (400 -> 448 instead of 512);
     // two to four workgroups per CU, so aim at ~1024 of them (tools/bench_bf16x3.py), never below 8 K-steps per split
     auto padded = [](int n, int t) { return (n + 64 * t - 1) / (64 * t) * (64 * t); };
@@ -438,7 +458,7 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
     }
     return CRADLE_OK;
   }
-  dim3 grid((unsigned)ntiles, 1, (unsigned)splitk);
+  dim3 grid((unsigned)ntiles, (unsigned)batch, (unsigned)splitk);
   bool ok;
   if (layout == 0) ok = launch_cfg<true, true>(p, ws, tm, tn, bk, depth, wk, aligned, grid, stream);
   else if (layout == 1) ok = launch_cfg<true, false>(p, ws, tm, tn, bk, depth, wk, aligned, grid, stream);
@@ -447,7 +467,7 @@ int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_float
   CRADLE_CHECK_LAUNCH("gemm_f32_kernel");
   if (splitk > 1) {
     const int64_t quads = (p.slab + 3) / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256), (unsigned)batch), dim3(256), 0, stream, p);
     CRADLE_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return CRADLE_OK;

@@ -37,6 +37,11 @@ struct GemmParams {
   int k_valid;            // > 0: rows/columns of the K axis that exist in memory (K itself may be padded up to a multiple
                           // of 4 by the caller: the operand extents then end at k_valid and the range check reads zeros)
   int precision;          // 0: fp32 MFMA (default); 1: split-bf16 (3 products) for products large enough to gain
+  // > 1: that many independent products of the same shape in ONE launch (grid y): problem b reads A + b * bs_a,
+  // B + b * bs_b and writes C + b * bs_c (and extra_col + b * bs_x); strides in floats, any sign.  Plain products only
+  // (fp32; of the epilogue features only extra_col): the weight gradients of an MLP's hidden layers.
+  int batch;
+  int64_t bs_a, bs_b, bs_c, bs_x;
 };
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 int gemm_f32(int layout, GemmParams p, float* workspace, int64_t workspace_floats, hipStream_t stream);

@@ -395,9 +395,30 @@ const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_p
     hipEvent_t e = c.record(q);
     c.wait(wq, e);
     if (wq2 != wq) c.wait(wq2, e);
-    for (int i = 0; i < n_pending; ++i) {
-      wgrad(pending[i], side);
+    // hidden layers have one shape: when their buffers are equally spaced (the workspace and the parameter arena lay
+    // them out that way) the pending weight gradients are ONE launch -- grid y = layer -- instead of one each
+    bool strided = n_pending > 1 && !(sched_flags() & 8);
+    int64_t sa = 0, sb = 0, sc = 0, sx = 0;
+    if (strided) {
+      const int k0 = pending[0], k1 = pending[1];
+      sa = da[k1] - da[k0]; sb = y[k1 - 1] - y[k0 - 1]; sc = g.W[k1] - g.W[k0]; sx = g.b[k1] - g.b[k0];
+      for (int i = 2; i < n_pending && strided; ++i) {
+        const int ka = pending[i - 1], kb = pending[i];
+        strided = da[kb] - da[ka] == sa && y[kb - 1] - y[ka - 1] == sb && g.W[kb] - g.W[ka] == sc && g.b[kb] - g.b[ka] == sx;
+      }
+    }
+    if (strided) {
+      const int k0 = pending[0];
+      GemmParams p = gp(da[k0], H, y[k0 - 1], H, g.W[k0], H, H, H, M);
+      p.extra_col = g.b[k0];
+      p.batch = n_pending; p.bs_a = sa; p.bs_b = sb; p.bs_c = sc; p.bs_x = sx;
+      c.gemm(GEMM_TN, p, side);
       side = side == wq ? wq2 : wq;
+    } else {
+      for (int i = 0; i < n_pending; ++i) {
+        wgrad(pending[i], side);
+        side = side == wq ? wq2 : wq;
+      }
     }
     n_pending = 0;
     if (ev_done) *ev_done = e;
