@@ -304,9 +304,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p_i
   const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (idx >= total) return;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int z = 0; z < p.splitk; ++z) {
-    const float4 t = *reinterpret_cast<const float4*>(p.partial + (int64_t)z * p.slab + idx);
-    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  // eight splits' loads in flight before the first add (the sum itself stays in split order: deterministic, and the
+  // same value whatever the batch of eight holds)
+  for (int z0 = 0; z0 < p.splitk; z0 += 8) {
+    float4 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      t[i] = z0 + i < p.splitk ? *reinterpret_cast<const float4*>(p.partial + (int64_t)(z0 + i) * p.slab + idx)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (z0 + i < p.splitk) { v.x += t[i].x; v.y += t[i].y; v.z += t[i].z; v.w += t[i].w; }
+    }
   }
   int row = (int)(idx / Np), col = (int)(idx % Np);
   int rows[4], cols[4];
