@@ -103,3 +103,18 @@ def test_three_genes_take_the_modular_path_and_say_so():
     lm.step = "fused"
     with pytest.raises(NotImplementedError, match="n_phenos=3 < 4"):
         lm.loss(**kw)
+
+
+def test_deeper_mlps_batch_their_weight_gradients():
+    """Three hidden layers in every MLP (the shipped configurations have one in the decoder and the basal encoder): the
+    hidden layers' weight gradients of each MLP then go out as batched GEMM launches (grid y = layer, csrc/gemm.hip
+    GemmParams::batch) with K = P*N and 3*P*N rows and a batched split-K reduction; every gradient against the fp64
+    oracle, at a mid and at a wider shape (both tile families)."""
+    from cradle_vae_amd import synthetic as syn
+
+    for base, n_cells, hidden, seed in (("mid", 64, 32, 11), ("mid", 256, 192, 12)):
+        shape = dataclasses.replace(syn.SHAPES[base], name=f"{base}_deep{hidden}", n_cells=n_cells, decoder_n_layers=3,
+                                    basal_encoder_n_layers=3, embedding_encoder_n_layers=5, decoder_n_hidden=hidden,
+                                    basal_encoder_n_hidden=hidden, embedding_encoder_n_hidden=hidden)
+        worst = compare_with_oracle(shape, 2, seed, compact=False, precisions=("f32",))
+        print(f"\n{shape.name}: worst relative L2 gradient error / loss error: {worst}")
