@@ -31,15 +31,33 @@ namespace cradle {
 
 constexpr int kWave = 64;
 
+// Wave-wide reductions on the DPP data path (six dependent VALU operations and one v_readlane) instead of six
+// ds_bpermute round trips through the LDS pipe: a row kernel does four of these per particle row, and with two
+// waves per SIMD nothing hides a shuffle's latency.  Every lane gets the result.
+//   quad_perm [1,0,3,2] -> quad_perm [2,3,0,1] -> row_half_mirror -> row_mirror: every lane holds its row's (16 lanes) value;
+//   row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3: lane 63 holds the wave's.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                               ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_move<0xB1, 0xF>(0.f, v);
+  v += dpp_move<0x4E, 0xF>(0.f, v);
+  v += dpp_move<0x141, 0xF>(0.f, v);
+  v += dpp_move<0x140, 0xF>(0.f, v);
+  v += dpp_move<0x142, 0xA>(0.f, v);
+  v += dpp_move<0x143, 0xC>(0.f, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  v = fmaxf(v, dpp_move<0xB1, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x4E, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x141, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x140, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_move<0x143, 0xC>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Block-wide reductions over NT threads (NT multiple of 64, <= 1024).  `slot` points at

@@ -69,6 +69,14 @@ int cradle_nb_logprob_fwd_bwd_timed(const float* logits, int64_t ld_logits, floa
 namespace cradle {
 int nb_dlogc_reduce(const float* workspace, int rows, int G, float* dlog_c, int accumulate, hipStream_t stream, int valid = -1);
 int nb_gene_consts_padded(const float* log_c, float* gene_consts, int G, int Gp, hipStream_t stream);
+// K1 of the training step in two launches: the particle-independent lgamma / digamma terms (side stream, forward
+// pass), then the rows kernel that reads them (nb_loss.hip)
+int nb_count_terms(const float* X, int64_t ldx, const float* gene_consts, float* workspace, int64_t workspace_floats,
+                   float* lg, int P, int N, int G, hipStream_t stream);
+int nb_logprob_fwd_bwd_pre(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits, const float* X,
+                           int64_t ldx, const float* lib, const float* gene_consts, const float* grow, float* out,
+                           float* workspace, int64_t workspace_floats, const float* lg, int P, int N, int G, void* ev_begin,
+                           void* ev_end, hipStream_t stream);
 
 // ---- elementwise.hip : plan / per-cell preparation
 struct DosagePlan {

@@ -22,7 +22,11 @@ namespace cradle {
 
 // TAIL: the gene count is not a multiple of 4 (Gv < G): the last 16-byte vector of a row is masked.  A separate
 // instantiation: the masks cost the aligned case 6 us of its 38 when they are compiled in (register pressure).
-template <int VPT, int NT, bool BWD, bool TAIL>
+// PRE (training step): the particle-independent terms were made beforehand by nb_count_terms_kernel -- the cell's
+// sum of L(x,c) is read from pre_lg[n] and psi(c+x) - psi(c) from the cell's own row of dlogc_part, which this
+// kernel overwrites with its result at the end.  The lgamma / digamma evaluation (branchy, ~a third of this
+// kernel's instructions at five particles per cell) then runs on a side stream during the forward pass.
+template <int VPT, int NT, bool BWD, bool TAIL, bool PRE = false>
 __global__ __launch_bounds__(NT) void nb_rows_kernel(
     const float* logits, int64_t ld_logits,       // (P*N, ld) rows r = p*N + n
     float* dlogits, int64_t ld_dlogits,           // BWD: gradient rows, may alias logits
@@ -32,7 +36,8 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
     const float* __restrict__ grow,               // BWD: (P*N) d loss / d out[r]
     float* __restrict__ out,                      // (P*N) sum_g log p
     float* __restrict__ dlogc_part,               // BWD: (N*PS, G) partial d loss / d log_c
-    int P, int N, int G, int PS, int Gv) {  // G: row length run (multiple of 4); Gv <= G: genes that exist
+    int P, int N, int G, int PS, int Gv,    // G: row length run (multiple of 4); Gv <= G: genes that exist
+    const float* __restrict__ pre_lg = nullptr) {  // PRE: (N) sum_g L(x[n,g], c[g])
   __shared__ float2 red[6][NT / 64];
   const int n = blockIdx.x;
   const int ps = blockIdx.y;
@@ -56,8 +61,13 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
     if (k < G4) {
       x[j] = TAIL ? mask_gene_tail(X4[k], k, Gv, 0.f) : X4[k];
       c[j] = C4[k];
-      const float4 lgc = LGC4[k];
       float4 dpsi = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PRE) {
+        if (BWD) dpsi = reinterpret_cast<const float4*>(dlogc_part + ((int64_t)n * PS + ps) * G)[k];
+        dmain[j] = make_float4(gsum * dpsi.x, gsum * dpsi.y, gsum * dpsi.z, gsum * dpsi.w);
+        continue;
+      }
+      const float4 lgc = LGC4[k];
       if (BWD) {
         const float4 psc = PSC4[k];
         lg_local += nb_lgamma_term<true>(x[j].x, c[j].x, lgc.x, psc.x, dpsi.x);
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
       dmain[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  const float LG = block_sum<NT>(lg_local, reinterpret_cast<float*>(red[5]));
+  const float LG = PRE ? pre_lg[n] : block_sum<NT>(lg_local, reinterpret_cast<float*>(red[5]));
 
   // ---- walk this block's particle rows, prefetching one row ahead
   float4 cur[VPT], nxt[VPT];
@@ -177,6 +187,36 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
   }
 }
 
+// The particle-independent terms of the likelihood, once per (cell, gene) ahead of nb_rows_kernel<PRE>: the cell's
+// sum of L(x,c) -> lg[n], and psi(c+x) - psi(c) -> the cell's PS partial rows of d log_c (each particle split reads
+// its own copy before it overwrites the row).  Same thread/gene assignment and summation order as the rows kernel's
+// own prologue with NT threads: the two forms give the same bits.
+template <int NT, bool TAIL>
+__global__ __launch_bounds__(NT) void nb_count_terms_kernel(const float* __restrict__ X, int64_t ldx,
+                                                             const float* __restrict__ gene_consts,
+                                                             float* __restrict__ dpsi_rows, float* __restrict__ lg, int G,
+                                                             int PS, int Gv) {
+  __shared__ float2 red[NT / 64];
+  const int n = blockIdx.x, tid = threadIdx.x, G4 = G >> 2;
+  const float4* X4 = reinterpret_cast<const float4*>(X + (int64_t)n * ldx);
+  const float4* C4 = reinterpret_cast<const float4*>(gene_consts);
+  const float4* LGC4 = reinterpret_cast<const float4*>(gene_consts + G);
+  const float4* PSC4 = reinterpret_cast<const float4*>(gene_consts + 2 * (int64_t)G);
+  float lg_local = 0.f;
+  for (int k = tid; k < G4; k += NT) {
+    const float4 x = TAIL ? mask_gene_tail(X4[k], k, Gv, 0.f) : X4[k];
+    const float4 c = C4[k], lgc = LGC4[k], psc = PSC4[k];
+    float4 dpsi;
+    lg_local += nb_lgamma_term<true>(x.x, c.x, lgc.x, psc.x, dpsi.x);
+    lg_local += nb_lgamma_term<true>(x.y, c.y, lgc.y, psc.y, dpsi.y);
+    lg_local += nb_lgamma_term<true>(x.z, c.z, lgc.z, psc.z, dpsi.z);
+    lg_local += nb_lgamma_term<true>(x.w, c.w, lgc.w, psc.w, dpsi.w);
+    for (int ps = 0; ps < PS; ++ps) reinterpret_cast<float4*>(dpsi_rows + ((int64_t)n * PS + ps) * G)[k] = dpsi;
+  }
+  const float LG = block_sum<NT>(lg_local, reinterpret_cast<float*>(red));
+  if (tid == 0) lg[n] = LG;
+}
+
 // Per-gene constants from log_concentration: c = exp(log_c), lgamma(c), digamma(c).
 // (mlp.py:160 `concentration = torch.exp(self.log_concentration)`.)  G threads, evaluated in
 // double so the fp32 constants are correctly rounded.
@@ -259,26 +299,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
 constexpr int kNbMaxGenes = 1024 * 4 * 4;
 static int g_nb_tune_nt = -1, g_nb_tune_ps = -1;
 
-template <bool BWD>
+static int nb_threads(int G4) {
+  if (g_nb_tune_nt > 0) return g_nb_tune_nt;
+  return G4 <= 256 * 5 ? 256 : (G4 <= 512 * 4 ? 512 : 1024);  // measured: tools/bench_nb.py
+}
+
+template <bool BWD, bool PRE = false>
 static int launch_nb_rows(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits,
                           const float* X, int64_t ldx, const float* lib, const float* gene_consts,
                           const float* grow, float* out, float* dlogc_part, int P, int N, int G, int PS, int Gv,
-                          hipStream_t stream) {
+                          hipStream_t stream, const float* pre_lg = nullptr) {
   const int G4 = G / 4;
   dim3 grid(N, PS);
 #define CRADLE_NB_LAUNCH(VPT, NT)                                                                            \
   do {                                                                                                       \
     if (Gv < G)                                                                                              \
-      hipLaunchKernelGGL((nb_rows_kernel<VPT, NT, BWD, true>), grid, dim3(NT), 0, stream, logits, ld_logits, \
-                         dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, dlogc_part, P, N, G, PS, Gv); \
+      hipLaunchKernelGGL((nb_rows_kernel<VPT, NT, BWD, true, PRE>), grid, dim3(NT), 0, stream, logits, ld_logits, \
+                         dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, dlogc_part, P, N, G, PS, Gv, pre_lg); \
     else                                                                                                     \
-      hipLaunchKernelGGL((nb_rows_kernel<VPT, NT, BWD, false>), grid, dim3(NT), 0, stream, logits, ld_logits, \
-                         dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, dlogc_part, P, N, G, PS, Gv); \
+      hipLaunchKernelGGL((nb_rows_kernel<VPT, NT, BWD, false, PRE>), grid, dim3(NT), 0, stream, logits, ld_logits, \
+                         dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, dlogc_part, P, N, G, PS, Gv, pre_lg); \
   } while (0)
   // thread count / values per thread: as many waves per CU as the register budget allows (all
   // workgroups of a 512-cell batch are then resident at once); override via cradle_nb_tune
-  int nt = g_nb_tune_nt;
-  if (nt <= 0) nt = G4 <= 256 * 5 ? 256 : (G4 <= 512 * 4 ? 512 : 1024);  // measured: tools/bench_nb.py
+  const int nt = nb_threads(G4);
   const int vpt = (G4 + nt - 1) / nt;
   bool launched = true;
   if (nt == 256 && vpt == 1) CRADLE_NB_LAUNCH(1, 256);
@@ -332,6 +376,57 @@ int nb_dlogc_reduce(const float* workspace, int rows, int G, float* dlog_c, int 
                      valid < 0 ? G : valid);
   CRADLE_CHECK_LAUNCH("colsum_kernel");
   return CRADLE_OK;
+}
+
+// The training step's form of K1 (kernels.h): nb_count_terms on a side stream during the forward pass, then
+// nb_logprob_fwd_bwd_pre where cradle_nb_logprob_fwd_bwd_timed would stand.  Same arguments and checks; `workspace`
+// carries psi(c+x) - psi(c) in (the N * particle_split partial rows of d log_c), `lg` (N) the cells' lgamma sums.
+int nb_count_terms(const float* X, int64_t ldx, const float* gene_consts, float* workspace, int64_t workspace_floats,
+                   float* lg, int P, int N, int G, hipStream_t stream) {
+  CRADLE_CHECK_ARG(X && gene_consts && workspace && lg && P > 0 && N > 0 && G > 0, "nb_count_terms: bad arguments");
+  const int Gp = (G + 3) & ~3, PS = cradle_nb_particle_split(P, N);
+  CRADLE_CHECK_ARG(ldx >= Gp && ldx % 4 == 0 && (uintptr_t)X % 16 == 0 && (uintptr_t)gene_consts % 16 == 0 &&
+                       (uintptr_t)workspace % 16 == 0 && workspace_floats >= (int64_t)N * PS * Gp,
+                   "nb_count_terms: X / gene_consts / workspace must be 16-byte aligned, ld %% 4 == 0, workspace >= %lld floats",
+                   (long long)((int64_t)N * PS * Gp));
+  // the thread count of the rows kernel (same gene-to-thread assignment: same summation order)
+  const int nt = nb_threads(Gp / 4);
+#define CRADLE_CT_LAUNCH(NT)                                                                                          \
+  do {                                                                                                                \
+    if (G < Gp)                                                                                                       \
+      hipLaunchKernelGGL((nb_count_terms_kernel<NT, true>), dim3(N), dim3(NT), 0, stream, X, ldx, gene_consts,        \
+                         workspace, lg, Gp, PS, G);                                                                   \
+    else                                                                                                              \
+      hipLaunchKernelGGL((nb_count_terms_kernel<NT, false>), dim3(N), dim3(NT), 0, stream, X, ldx, gene_consts,       \
+                         workspace, lg, Gp, PS, G);                                                                   \
+  } while (0)
+  if (nt == 256) CRADLE_CT_LAUNCH(256);
+  else if (nt == 512) CRADLE_CT_LAUNCH(512);
+  else CRADLE_CT_LAUNCH(1024);
+#undef CRADLE_CT_LAUNCH
+  CRADLE_CHECK_LAUNCH("nb_count_terms_kernel");
+  return CRADLE_OK;
+}
+
+int nb_logprob_fwd_bwd_pre(const float* logits, int64_t ld_logits, float* dlogits, int64_t ld_dlogits, const float* X,
+                           int64_t ldx, const float* lib, const float* gene_consts, const float* grow, float* out,
+                           float* workspace, int64_t workspace_floats, const float* lg, int P, int N, int G, void* ev_begin,
+                           void* ev_end, hipStream_t stream) {
+  int rc = check_common(logits, X, lib, gene_consts, out, P, N, G, ld_logits, ldx);
+  if (rc) return rc;
+  CRADLE_CHECK_ARG(dlogits && grow && workspace && lg, "nb_logprob_fwd_bwd_pre: null pointer argument");
+  const int Gp = (G + 3) & ~3;
+  CRADLE_CHECK_ARG(ld_dlogits >= Gp && ld_dlogits % 4 == 0 && (uintptr_t)dlogits % 16 == 0,
+                   "nb_logprob_fwd_bwd_pre: dlogits must be 16-byte aligned with ld %% 4 == 0, ld >= n_genes rounded up to 4");
+  const int PS = cradle_nb_particle_split(P, N);
+  CRADLE_CHECK_ARG(workspace_floats >= (int64_t)N * PS * Gp && (uintptr_t)workspace % 16 == 0,
+                   "nb_logprob_fwd_bwd_pre: workspace needs %lld floats, 16-byte aligned (got %lld)",
+                   (long long)((int64_t)N * PS * Gp), (long long)workspace_floats);
+  if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, stream);
+  rc = launch_nb_rows<true, true>(logits, ld_logits, dlogits, ld_dlogits, X, ldx, lib, gene_consts, grow, out, workspace,
+                                  P, N, Gp, PS, G, stream, lg);
+  if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, stream);
+  return rc;
 }
 
 int nb_gene_consts_padded(const float* log_c, float* gene_consts, int G, int Gp, hipStream_t stream) {

@@ -72,7 +72,7 @@ struct Work {
   float *yq[CRADLE_MAX_LAYERS], *rq[CRADLE_MAX_LAYERS], *headsq, *sdq, *qcE, *Sq, *qsum, *ones_q;
   float *xn, *Xp, *xW, *offB, *zoff, *offW, *vq;
   float *yz[CRADLE_MAX_LAYERS], *rz[CRADLE_MAX_LAYERS], *headsz, *sdz, *ltz, *klrow;
-  float *wq, *yd[CRADLE_MAX_LAYERS], *rd[CRADLE_MAX_LAYERS], *logits, *recon, *nbws;
+  float *wq, *yd[CRADLE_MAX_LAYERS], *rd[CRADLE_MAX_LAYERS], *logits, *recon, *nbws, *nb_lg;
   // backward
   // backward: G ping-pongs on the main stream; the pre-activation gradients da[k] are kept per
   // layer because the weight-gradient GEMMs read them from a side stream
@@ -178,6 +178,7 @@ int64_t carve(const cradle_step_desc& d, void* base, Work& w) {
   w.recon = a.take<float>(PN);
   w.nbws_floats = cradle_nb_workspace_floats(P, N, Gp);
   w.nbws = a.take<float>(w.nbws_floats);
+  w.nb_lg = a.take<float>(N);
   for (int i = 0; i < 2; ++i) {
     w.Gd[i] = a.take<float>(PN * Hd);
     w.Gz[i] = a.take<float>(3 * PN * He);
@@ -546,6 +547,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   const float* nz_q = own_noise ? w.eps_qc_E : d.eps_qc_E;
   const float* nz_z = own_noise ? w.eps_z : d.eps_z;
   const bool qc_fused = qc_chain_supported(Q, L, Hm, PP) && !(sched_flags() & 4);
+  const bool nb_pre = d.compute_grads && !(sched_flags() & 16);
 #define STEP(call)        \
   do {                    \
     rc = (call);          \
@@ -583,6 +585,11 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   STEP(build_dosage_plan_csc(N, T, w.plan, s1));
   STEP(cell_prep(d.qc, d.D_obs_counts, d.qc_obs_counts, w.plan.tcount, d.alpha, P, N, T, Q, w.cp, d.flags, Tc, w.plan.tmap,
                  s1));
+  // K1's particle-independent terms (per-gene constants, then the lgamma / digamma terms of every count): behind
+  // everything stream 1 owes the encoders, long before the decoder joins it (CRADLE_SCHED bit 16: inside K1 instead)
+  STEP(nb_gene_consts_padded(d.log_concentration, w.gene_consts, G, Gp, s1));
+  if (nb_pre)
+    STEP(nb_count_terms(w.Xp ? w.Xp : d.X, Gp, w.gene_consts, w.nbws, w.nbws_floats, w.nb_lg, P, N, G, s1));
   // the step's own noise: q(qc_E)'s on the stream that reads it, the rest on the caller's -- no event between them
   // Compact treatment axis: u_mask / eps_E are (2P, T, L), but only the rows of the treatments in the batch are ever
   // read -- those are drawn once the slot map exists (below), the same values at the same places
@@ -620,7 +627,6 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   c.gemm(GEMM_NT, gp(w.qcE, L, Wenc0 + G + L, ldenc, w.vq, He, PP * Q, He, L), 2);  // qc_E Wqc^T
   ev_vq = c.record(2);
   c.gemm(GEMM_NT, gp(w.qsum, L, Wd0 + 2 * L, 3 * L, w.wq, Hd, P, Hd, L), 2);        // bad-variant shift per particle
-  STEP(nb_gene_consts_padded(d.log_concentration, w.gene_consts, G, Gp, s2));
   hipEvent_t ev_s2 = c.record(2);
 
   if (w.plan.tmap) c.wait(0, ev_plan);
@@ -689,9 +695,13 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
     STEP(cradle_nb_logprob_fwd(w.logits, Gp, Xk, Gp, d.library_size, w.gene_consts, w.recon, P, N, G, s));
     if (d.ev_k1_end) (void)hipEventRecord((hipEvent_t)d.ev_k1_end, s);
   } else {  // events bracket the rows kernel only (the launch the roofline in bench.py describes)
-    STEP(cradle_nb_logprob_fwd_bwd_timed(w.logits, Gp, w.logits, Gp, Xk, Gp, d.library_size, w.gene_consts, w.cp.grow,
-                                         w.recon, nullptr, 0, w.nbws, w.nbws_floats, P, N, G, d.ev_k1_begin,
-                                         d.ev_k1_end, s));
+    if (nb_pre)
+      STEP(nb_logprob_fwd_bwd_pre(w.logits, Gp, w.logits, Gp, Xk, Gp, d.library_size, w.gene_consts, w.cp.grow, w.recon,
+                                  w.nbws, w.nbws_floats, w.nb_lg, P, N, G, d.ev_k1_begin, d.ev_k1_end, s));
+    else
+      STEP(cradle_nb_logprob_fwd_bwd_timed(w.logits, Gp, w.logits, Gp, Xk, Gp, d.library_size, w.gene_consts, w.cp.grow,
+                                           w.recon, nullptr, 0, w.nbws, w.nbws_floats, P, N, G, d.ev_k1_begin,
+                                           d.ev_k1_end, s));
   }
   }
   // the loss scalars, d log_c and the q(E|M) bookkeeping are leaves of the graph: stream 2, beside the backward
