@@ -118,14 +118,24 @@ __device__ __forceinline__ float sample_nb_inversion(float c, float y, float neg
   float cdf = pk, k = 0.f;
   if (u > cdf) {
     const float q = y * __frcp_rn(1.0f + y);  // 1/(1+rate)
+    const float cq = c * q;
     const float kmode = (c - 1.0f) * y;       // the pmf rises up to here: never stop the search before it
-    // past the mode, stop once the increments no longer move the cdf: u is beyond what fp32 resolves
+    // Four steps per turn of the loop: a step is one compare and five operations under the lane's own predicate
+    // (pmf(k+1) = pmf(k) (k q + c q) / (k+1)); the four reciprocals come as one 16-byte LDS read, and what does not
+    // change the draw -- the test that stops a search whose u lies beyond what the fp32 cdf can reach (past the mode,
+    // increments below 1e-9) and the iteration cap -- is looked at once per turn, not once per step.  The loop runs
+    // as long as the slowest lane of the wave: its cost per step is what counts.
+    const float4* inv4 = reinterpret_cast<const float4*>(inv_tab);
     int ki = 0;
-    while (u > cdf && (k <= kmode || pk > 1e-9f) && ki < 512) {
-      pk *= (k + c) * q * inv_tab[ki];
+    bool live = true;
+    while (live) {
+      const float4 iv = inv4[ki];
+      if (u > cdf) { pk *= fmaf(k, q, cq) * iv.x; cdf += pk; k += 1.0f; }
+      if (u > cdf) { pk *= fmaf(k, q, cq) * iv.y; cdf += pk; k += 1.0f; }
+      if (u > cdf) { pk *= fmaf(k, q, cq) * iv.z; cdf += pk; k += 1.0f; }
+      if (u > cdf) { pk *= fmaf(k, q, cq) * iv.w; cdf += pk; k += 1.0f; }
       ++ki;
-      k += 1.0f;
-      cdf += pk;
+      live = u > cdf && (k <= kmode || pk > 1e-9f) && ki < 128;
     }
   }
   return k;
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(NT) void nb_sample_accumulate_kernel(const float* _
   float* slot = dyn_lds;                                  // [G]
   int* queue = reinterpret_cast<int*>(dyn_lds + G);       // [G]
   __shared__ int queued;
-  __shared__ float inv_tab[512];
+  __shared__ __attribute__((aligned(16))) float inv_tab[512];
   for (int i = threadIdx.x; i < 512; i += NT) inv_tab[i] = 1.0f / (float)(i + 1);  // (visible after the first softmax barrier)
   const int t = blockIdx.x, tid = threadIdx.x;
   const int G4 = G >> 2;
