@@ -29,23 +29,23 @@ namespace cradle {
 
 // Gamma(shape a, scale 1): Marsaglia-Tsang with the a < 1 boost; bounded rejection loop.
 __device__ float sample_gamma(float a, const Philox& ph, uint32_t gene, uint32_t row, uint32_t& draw) {
-  float boost = 1.0f;
-  if (a < 1.0f) {
-    const uint4 r = ph(gene, row, draw++, 1u);
-    boost = __powf(u01(r.x), 1.0f / a);
-    a += 1.0f;
-  }
+  const bool small = a < 1.0f;
+  const float a0 = a;
+  if (small) a += 1.0f;
   const float d = a - 1.0f / 3.0f, c = rsqrtf(9.0f * d);
-  float out = d;
+  float out = d, boost = 1.0f;
   for (int it = 0; it < 16; ++it) {
     const uint4 r = ph(gene, row, draw++, 2u);
+    if (it == 0 && small) boost = __powf(u01(r.w), 1.0f / a0);  // the a < 1 boost U^(1/a): the call's fourth word
     const float rad = sqrtf(-2.0f * __logf(u01(r.x)));
     const float x = rad * __cosf(6.283185307179586f * u01(r.y));
     const float t = 1.0f + c * x;
     if (t <= 0.f) continue;
     const float v = t * t * t;
     const float u = u01(r.z);
-    if (__logf(u) < 0.5f * x * x + d - d * v + d * __logf(v)) {
+    const float x2 = x * x;
+    // squeeze (Marsaglia & Tsang): accepts ~98 % of the proposals without the two logarithms
+    if (u < 1.0f - 0.0331f * x2 * x2 || __logf(u) < 0.5f * x2 + d - d * v + d * __logf(v)) {
       out = d * v;
       break;
     }
@@ -53,22 +53,8 @@ __device__ float sample_gamma(float a, const Philox& ph, uint32_t gene, uint32_t
   return out * boost;
 }
 
-// Poisson(lam): multiplication method below 10, Hoermann's PTRS above (as torch.poisson does).
-__device__ float sample_poisson(float lam, const Philox& ph, uint32_t gene, uint32_t row, uint32_t& draw) {
-  if (!(lam > 0.f)) return 0.f;
-  if (lam < 10.f) {
-    const float L = __expf(-lam);
-    float p = 1.0f;
-    int k = 0;
-    for (int it = 0; it < 32; ++it) {  // 4 uniforms per Philox call; P(k > 127 | lam < 10) ~ 0
-      const uint4 r = ph(gene, row, draw++, 3u);
-      p *= u01(r.x); if (p <= L) return (float)k; ++k;
-      p *= u01(r.y); if (p <= L) return (float)k; ++k;
-      p *= u01(r.z); if (p <= L) return (float)k; ++k;
-      p *= u01(r.w); if (p <= L) return (float)k; ++k;
-    }
-    return (float)k;
-  }
+// Poisson(lam), lam >= 10: Hoermann's PTRS (as torch.poisson does).
+__device__ float sample_poisson_ptrs(float lam, const Philox& ph, uint32_t gene, uint32_t row, uint32_t& draw) {
   const float slam = sqrtf(lam), loglam = __logf(lam);
   const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
   const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.0f);
@@ -84,12 +70,42 @@ __device__ float sample_poisson(float lam, const Philox& ph, uint32_t gene, uint
   return floorf(lam);
 }
 
+// Poisson(lam), lam < kPoisSearchMax: inversion by sequential search from pmf(0) = exp(-lam) >= 4.5e-5, one uniform,
+// pmf(k+1) = pmf(k) lam / (k+1) -- four steps per loop turn like sample_nb_inversion below (same table).
+constexpr float kPoisSearchMax = 10.0f;
+__device__ __forceinline__ float sample_poisson_search(float lam, float u, const float* __restrict__ inv_tab) {
+  float pk = __expf(-lam), cdf = pk, k = 0.f;
+  if (!(lam > 0.f)) return 0.f;
+  const float4* inv4 = reinterpret_cast<const float4*>(inv_tab);
+  int ki = 0;
+  bool live = u > cdf;
+  while (live) {
+    const float4 iv = inv4[ki];
+    if (u > cdf) { pk *= lam * iv.x; cdf += pk; k += 1.0f; }
+    if (u > cdf) { pk *= lam * iv.y; cdf += pk; k += 1.0f; }
+    if (u > cdf) { pk *= lam * iv.z; cdf += pk; k += 1.0f; }
+    if (u > cdf) { pk *= lam * iv.w; cdf += pk; k += 1.0f; }
+    ++ki;
+    live = u > cdf && (k <= lam || pk > 1e-9f) && ki < 128;  // past the mode with increments fp32 no longer sees: stop
+  }
+  return k;
+}
+
+// Poisson(lam) where it is met (the path that does not re-queue: more than half of a row's genes deferred)
+__device__ float sample_poisson(float lam, const Philox& ph, uint32_t gene, uint32_t row, uint32_t& draw,
+                                const float* __restrict__ inv_tab) {
+  if (!(lam > 0.f)) return 0.f;
+  if (lam < kPoisSearchMax) return sample_poisson_search(lam, u01(ph(gene, row, 0u, 3u).x), inv_tab);
+  return sample_poisson_ptrs(lam, ph, gene, row, draw);
+}
+
 // The Gamma -> Poisson composition (pyro GammaPoisson.sample).  Not inlined: it is the rare branch
 // of the kernel's gene loop, which must stay small enough to unroll (v[], c[] live in registers).
-__device__ __noinline__ float sample_gamma_poisson(float c, float rate, Philox ph, uint32_t gene, uint32_t row) {
+__device__ __noinline__ float sample_gamma_poisson(float c, float rate, Philox ph, uint32_t gene, uint32_t row,
+                                                   const float* __restrict__ inv_tab) {
   uint32_t draw = 0;
   const float lam = sample_gamma(c, ph, gene, row, draw) / rate;
-  return sample_poisson(lam, ph, gene, row, draw);
+  return sample_poisson(lam, ph, gene, row, draw, inv_tab);
 }
 
 // NegBinomial(c, rate) by inversion (sequential search upwards from 0).  Usable where
@@ -167,13 +183,13 @@ __global__ __launch_bounds__(NT) void nb_sample_accumulate_kernel(const float* _
   extern __shared__ float dyn_lds[];
   float* slot = dyn_lds;                                  // [G]
   int* queue = reinterpret_cast<int*>(dyn_lds + G);       // [G]
-  __shared__ int queued;
+  __shared__ int queued, queued_b;
   __shared__ __attribute__((aligned(16))) float inv_tab[512];
   for (int i = threadIdx.x; i < 512; i += NT) inv_tab[i] = 1.0f / (float)(i + 1);  // (visible after the first softmax barrier)
   const int t = blockIdx.x, tid = threadIdx.x;
   const int G4 = G >> 2;
   const Philox ph{seed_lo, seed_hi};
-  if (tid == 0) queued = 0;  // (the first push comes after the barriers of the first row's softmax)
+  if (tid == 0) queued = queued_b = 0;  // (the first push comes after the barriers of the first row's softmax)
   const float libt = lib[lib_n == 1 ? 0 : t];
   float4 c[VPT], acc[VPT];
 #pragma unroll
@@ -243,12 +259,37 @@ __global__ __launch_bounds__(NT) void nb_sample_accumulate_kernel(const float* _
     if (sampler == SAMPLER_NB) {
       __syncthreads();
       const int n_queued = queued;
-      for (int i = tid; i < n_queued; i += NT) {
-        const int g = queue[i];
-        slot[g] = sample_gamma_poisson(gene_consts[g], slot[g], ph, (uint32_t)g, row);
+      if (2 * n_queued <= G) {
+        // Phases, so that the lanes of a wave do the same thing: (a) every queued gene's Gamma draw; rates of 10 and
+        // more take their Poisson draw (PTRS) at once, the others go to a second queue (filled from the back of
+        // queue[]: n_queued entries at the front, at most as many at the back); (b) the second queue's Poisson draws
+        // by sequential search.  (One pass with both Poisson forms and the search inside it costs a wave the sum of
+        // all branches whenever its lanes differ -- they always do.)
+        for (int i = tid; i < n_queued; i += NT) {
+          const int g = queue[i];
+          uint32_t draw = 0;
+          const float lam = sample_gamma(gene_consts[g], ph, (uint32_t)g, row, draw) / slot[g];
+          if (lam < kPoisSearchMax) {
+            slot[g] = lam;
+            queue[G - 1 - atomicAdd(&queued_b, 1)] = g;
+          } else {
+            slot[g] = sample_poisson_ptrs(lam, ph, (uint32_t)g, row, draw);
+          }
+        }
+        __syncthreads();
+        const int n_b = queued_b;
+        for (int i = tid; i < n_b; i += NT) {
+          const int g = queue[G - 1 - i];
+          slot[g] = sample_poisson_search(slot[g], u01(ph((uint32_t)g, row, 0u, 3u).x), inv_tab);
+        }
+      } else {
+        for (int i = tid; i < n_queued; i += NT) {
+          const int g = queue[i];
+          slot[g] = sample_gamma_poisson(gene_consts[g], slot[g], ph, (uint32_t)g, row, inv_tab);
+        }
       }
       __syncthreads();
-      if (tid == 0) queued = 0;  // the next row pushes only after the two barriers of its softmax
+      if (tid == 0) queued = queued_b = 0;  // the next row pushes only after the two barriers of its softmax
 #pragma unroll
       for (int j = 0; j < VPT; ++j) {
         float* e = reinterpret_cast<float*>(&v[j]);
