@@ -4,8 +4,8 @@
 // (cradle_vae/data/utils/perturbation_dataset.py:44-89: X[idx], D[idx], qc[idx], cfX[idx], library_size[idx], all fp32,
 // collated on the host and copied to the device every step).  Here the data set stays on the GPU in its compact form --
 // counts as uint8 / int16 / int32 (they are integer-valued), D as <= kmax (treatment, dosage) pairs per cell -- and one
-// launch gathers the rows of a shuffled index batch into the dense fp32 tensors of the batch contract; a second,
-// single-workgroup launch counts the distinct treatments in the batch (cradle_step_desc.max_present).
+// launch gathers the rows of a shuffled index batch into the dense fp32 tensors of the batch contract; a second
+// launch counts the distinct treatments in the batch (cradle_step_desc.max_present).
 // HBM-bound: one workgroup per cell streams the cell's two count rows (G values each) and writes 8 G + 4 T bytes.
 #include "common.h"
 #include "kernels.h"
@@ -61,29 +61,20 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const cradle_batch_de
   }
 }
 
-// (D != 0).any(0).sum() of the gathered batch: a bitmap over treatments in LDS, one workgroup.
+// (D != 0).any(0).sum() of the gathered batch from the (treatment, dosage) pairs: a bitmap over treatments in LDS,
+// one workgroup (N * kmax pairs).
 __global__ __launch_bounds__(1024) void count_present_kernel(const cradle_batch_desc d, int words) {
   extern __shared__ unsigned int bits[];
   __shared__ int total;
   for (int w = threadIdx.x; w < words; w += 1024) bits[w] = 0u;
   if (threadIdx.x == 0) total = 0;
   __syncthreads();
-  auto stored_row = [&](int n) {
-    const int64_t r = d.pos[n];
-    return (d.rows > 0 && (r < 0 || r >= d.rows)) ? (int64_t)0 : r;
-  };
-  if (d.d_dense) {
-    const int64_t n_el = (int64_t)d.N * d.T;
-    for (int64_t i = threadIdx.x; i < n_el; i += 1024) {
-      const int t = (int)(i % d.T);
-      if (d.d_dense[stored_row((int)(i / d.T)) * d.T + t] != 0.f) atomicOr(&bits[t >> 5], 1u << (t & 31));
-    }
-  } else {
-    for (int i = threadIdx.x; i < d.N * d.kmax; i += 1024) {
-      const int64_t e = stored_row(i / d.kmax) * d.kmax + i % d.kmax;
-      const int t = d.d_idx[e];
-      if (t >= 0 && t < d.T && d.d_val[e] != 0.f) atomicOr(&bits[t >> 5], 1u << (t & 31));
-    }
+  for (int i = threadIdx.x; i < d.N * d.kmax; i += 1024) {
+    int64_t r = d.pos[i / d.kmax];
+    if (d.rows > 0 && (r < 0 || r >= d.rows)) r = 0;
+    const int64_t e = r * d.kmax + i % d.kmax;
+    const int t = d.d_idx[e];
+    if (t >= 0 && t < d.T && d.d_val[e] != 0.f) atomicOr(&bits[t >> 5], 1u << (t & 31));
   }
   __syncthreads();
   int c = 0;
@@ -92,6 +83,31 @@ __global__ __launch_bounds__(1024) void count_present_kernel(const cradle_batch_
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(&total, c);
   __syncthreads();
   if (threadIdx.x == 0) *d.present_out = total;
+}
+
+// The same from dense stored dosages (N x T elements: 5 M at 512 x 10 000): a workgroup owns 256 treatments, its 1024
+// threads walk the batch four cells at a time (256-column row segments: coalesced), and the workgroups' counts meet in
+// present_out (cleared by the host side beforehand; integer adds: any order gives the same sum).
+__global__ __launch_bounds__(1024) void count_present_dense_kernel(const cradle_batch_desc d) {
+  __shared__ int seen[256];
+  const int col = threadIdx.x & 255, sub = threadIdx.x >> 8;
+  const int t = blockIdx.x * 256 + col;
+  if (threadIdx.x < 256) seen[threadIdx.x] = 0;
+  __syncthreads();
+  bool any = false;
+  if (t < d.T) {
+    for (int n = sub; n < d.N; n += 4) {
+      int64_t r = d.pos[n];
+      if (d.rows > 0 && (r < 0 || r >= d.rows)) r = 0;
+      any |= d.d_dense[r * d.T + t] != 0.f;
+    }
+  }
+  if (any) seen[col] = 1;  // (every writer stores the same value)
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int c = (int)wave_sum((float)seen[threadIdx.x]);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(d.present_out, c);
+  }
 }
 
 }  // namespace cradle
@@ -115,10 +131,19 @@ extern "C" int cradle_gather_batch(const cradle_batch_desc* d, hipStream_t strea
   hipLaunchKernelGGL(gather_batch_kernel, dim3(d->N), dim3(256), 0, stream, *d);
   CRADLE_CHECK_LAUNCH("gather_batch_kernel");
   if (d->present_out) {
-    const int words = (d->T + 31) / 32;
-    CRADLE_CHECK_ARG((size_t)words * 4 <= 60 * 1024, "gather_batch: n_treatments=%d too many for the presence bitmap", d->T);
-    hipLaunchKernelGGL(count_present_kernel, dim3(1), dim3(1024), (size_t)words * 4, stream, *d, words);
-    CRADLE_CHECK_LAUNCH("count_present_kernel");
+    if (d->d_dense) {
+      if (hipMemsetAsync(d->present_out, 0, sizeof(int), stream) != hipSuccess) {
+        cradle_set_error("gather_batch: clearing the treatment count failed");
+        return CRADLE_ERR_HIP;
+      }
+      hipLaunchKernelGGL(count_present_dense_kernel, dim3((d->T + 255) / 256), dim3(1024), 0, stream, *d);
+      CRADLE_CHECK_LAUNCH("count_present_dense_kernel");
+    } else {
+      const int words = (d->T + 31) / 32;
+      CRADLE_CHECK_ARG((size_t)words * 4 <= 60 * 1024, "gather_batch: n_treatments=%d too many for the presence bitmap", d->T);
+      hipLaunchKernelGGL(count_present_kernel, dim3(1), dim3(1024), (size_t)words * 4, stream, *d, words);
+      CRADLE_CHECK_LAUNCH("count_present_kernel");
+    }
   }
   return CRADLE_OK;
 }

@@ -32,6 +32,7 @@ def _dataset(n, G, T, Q, xmax, cfmax, seed, fractional=False):
     (301, 37, 2, 30000, 300, True, False),   # int16 / int16, widths that are not multiples of 4
     (128, 2000, 1, 100000, 7, True, False),  # int32 / uint8, more treatments than cells
     (96, 50, 1, 50, 50, False, False),       # dense D as the reference stores it
+    (64, 700, 1, 50, 50, False, False),      # dense D, treatments over three workgroups of the presence count
     (100, 33, 1, 50, 5, True, True),         # non-integer X: stays fp32
 ])
 def test_hip_gather_equals_the_torch_loader(G, T, Q, xmax, cfmax, sparse, fractional, monkeypatch):
