@@ -12,6 +12,8 @@ they are dealt round-robin to the ranks and the sums meet in one all-reduce.
 """
 from __future__ import annotations
 
+import contextlib
+
 from typing import Dict, List, Literal, Optional, Sequence
 
 import numpy as np
@@ -81,47 +83,49 @@ def estimate_model_average_treatment_effect(
 
     world, rank = parallel.world_and_rank()
     starts = list(range(0, n_particles, batch_size))
-    for ci in parallel.my_chunks(len(starts), world, rank):
-        i = starts[ci]
-        c = min(batch_size, n_particles - i)
-        gen = _chunk_generator(device, seed, ci)
-        nz = {}
-        if noise_chunks is not None:
-            nz = {k: v.to(device=device, dtype=torch.float32) for k, v in noise_chunks[ci].items()}
-        plated_cv = {k: v for k, v in cv.items() if k in ("mask", "E", "qc_E")}
-        # :143-145; draws that are not injected come from this chunk's generator inside the guide (in slabs of
-        # treatments when there are thousands: no (c, T, L) noise tensors up front)
-        _, gs = guide(n_particles=c, condition_values=plated_cv, noise=nz, generator=gen)
-        EM = gs["E"] * gs["mask"] if "E" in plated_cv else gs["E"].mul_(gs["mask"])  # in place: E is this call's own
-        del gs
-        # conditions in slabs so that one decoder pass stays within MAX_ROWS_PER_LAUNCH rows
-        slab = max(1, min(MAX_ROWS_PER_LAUNCH, MAX_LOGIT_FLOATS // G) // c)
-        slab = -(-C // -(-C // slab))  # equal slabs: 237 conditions go as 119 + 118, not 209 + 28 (a small GEMM tail)
-        z_shared = None
-        for s0 in range(0, C, slab):
-            s1 = min(C, s0 + slab)
-            n = s1 - s0
-            if "z_basal" in cv:
-                z = cv["z_basal"].to(device)
-                z = (z.unsqueeze(0) if z.dim() == 2 else z).expand(c, -1, -1)
-                z = z.expand(c, C, L)[:, s0:s1] if z.shape[1] == 1 else z[:, s0:s1]
-            elif "z_control" in nz:
-                zc, za = nz["z_control"], nz["z_alt"]  # (c,1,L), (n_alt,c,1,L)
-                z_all = zc.expand(c, C, L) if share_z else torch.cat([zc, za[:, :, 0, :].permute(1, 0, 2)], dim=1)
-                z = z_all[:, s0:s1]
-            elif share_z:  # :165-167: z_basal of the control call is reused for every alternative
-                if z_shared is None:
-                    z_shared = torch.randn((c, 1, L), device=device, generator=gen)
-                z = z_shared.expand(c, n, L)
-            else:  # p_z_basal = Normal(0, 1) drawn per call (model.py:82)
-                z = torch.randn((c, n, L), device=device, generator=gen)
-            off = (F_hip.dosage_matmul(plan.rows(s0, s1), EM, c) if plan is not None
-                   else F_hip.dense_dosage_matmul(D_all[s0:s1], EM, c))
-            z_good = torch.cat([z, off, torch.zeros((c, n, L), device=device)], dim=-1)  # model.py:121
-            p_x_good = model.decoder(z_good, lib)
-            call_seed = (seed * 7919 + ci) * 4099 + s0
-            ops.nb_sample_accumulate(
-                p_x_good.logits, lib, gene_consts, c, n, sums=sums[s0:s1], method=method, sampler=sampler, seed=call_seed)
+    # q(qc_E)'s mean and scale once for the whole call, not once per particle chunk (guide.frozen_qc_dist)
+    with guide.frozen_qc_dist() if hasattr(guide, "frozen_qc_dist") else contextlib.nullcontext():
+        for ci in parallel.my_chunks(len(starts), world, rank):
+            i = starts[ci]
+            c = min(batch_size, n_particles - i)
+            gen = _chunk_generator(device, seed, ci)
+            nz = {}
+            if noise_chunks is not None:
+                nz = {k: v.to(device=device, dtype=torch.float32) for k, v in noise_chunks[ci].items()}
+            plated_cv = {k: v for k, v in cv.items() if k in ("mask", "E", "qc_E")}
+            # :143-145; draws that are not injected come from this chunk's generator inside the guide (in slabs of
+            # treatments when there are thousands: no (c, T, L) noise tensors up front)
+            _, gs = guide(n_particles=c, condition_values=plated_cv, noise=nz, generator=gen)
+            EM = gs["E"] * gs["mask"] if "E" in plated_cv else gs["E"].mul_(gs["mask"])  # in place: E is this call's own
+            del gs
+            # conditions in slabs so that one decoder pass stays within MAX_ROWS_PER_LAUNCH rows
+            slab = max(1, min(MAX_ROWS_PER_LAUNCH, MAX_LOGIT_FLOATS // G) // c)
+            slab = -(-C // -(-C // slab))  # equal slabs: 237 conditions go as 119 + 118, not 209 + 28 (a small GEMM tail)
+            z_shared = None
+            for s0 in range(0, C, slab):
+                s1 = min(C, s0 + slab)
+                n = s1 - s0
+                if "z_basal" in cv:
+                    z = cv["z_basal"].to(device)
+                    z = (z.unsqueeze(0) if z.dim() == 2 else z).expand(c, -1, -1)
+                    z = z.expand(c, C, L)[:, s0:s1] if z.shape[1] == 1 else z[:, s0:s1]
+                elif "z_control" in nz:
+                    zc, za = nz["z_control"], nz["z_alt"]  # (c,1,L), (n_alt,c,1,L)
+                    z_all = zc.expand(c, C, L) if share_z else torch.cat([zc, za[:, :, 0, :].permute(1, 0, 2)], dim=1)
+                    z = z_all[:, s0:s1]
+                elif share_z:  # :165-167: z_basal of the control call is reused for every alternative
+                    if z_shared is None:
+                        z_shared = torch.randn((c, 1, L), device=device, generator=gen)
+                    z = z_shared.expand(c, n, L)
+                else:  # p_z_basal = Normal(0, 1) drawn per call (model.py:82)
+                    z = torch.randn((c, n, L), device=device, generator=gen)
+                off = (F_hip.dosage_matmul(plan.rows(s0, s1), EM, c) if plan is not None
+                       else F_hip.dense_dosage_matmul(D_all[s0:s1], EM, c))
+                z_good = torch.cat([z, off, torch.zeros((c, n, L), device=device)], dim=-1)  # model.py:121
+                p_x_good = model.decoder(z_good, lib)
+                call_seed = (seed * 7919 + ci) * 4099 + s0
+                ops.nb_sample_accumulate(
+                    p_x_good.logits, lib, gene_consts, c, n, sums=sums[s0:s1], method=method, sampler=sampler, seed=call_seed)
     parallel.allreduce_sum_(sums_rows, world)
     means = sums / n_particles  # :199-200
     return (means[1:] - means[:1]).cpu().numpy()

@@ -3,6 +3,8 @@
 correlated_normal_guide.py:18-215) on the HIP kernels."""
 from __future__ import annotations
 
+import contextlib
+
 from dataclasses import dataclass
 from typing import Dict, Literal, Optional, Tuple
 
@@ -93,9 +95,25 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
         self.max_dosages_per_cell = 8
         self.dense_dosage_matmul = False
         self.dosage_overflow = None
+        self._qc_dist_cache = None
 
     def get_var_keys(self):
         return ["z_basal", "E", "mask", "qc_E"]
+
+    @contextlib.contextmanager
+    def frozen_qc_dist(self):
+        """Inference loops that call the guide many times with unchanged parameters (the ATE estimator: once per
+        particle chunk): q(qc_E) does not depend on the call -- its encoder's input is the constant ones(Q, L)
+        (correlated_normal_guide.py:162-166) -- so its mean and scale are evaluated once, on the Q rows, and reused
+        inside the block; the reference pushes P identical rows through the encoder in every call.  Same values:
+        a row's result does not depend on how many copies of it the product holds."""
+        with torch.no_grad():
+            q = self.qc_encoder(self.qc_encoder_input.unsqueeze(0))
+            self._qc_dist_cache = (q.mean[0].contiguous(), q.stddev[0].contiguous())
+        try:
+            yield
+        finally:
+            self._qc_dist_cache = None
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         if self.n_treatments > MAX_ONE_HOT_BUFFER:  # a reference checkpoint carries eye(T): not needed here
@@ -170,7 +188,11 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
                     E[:, t0:t1] = qE.mean + qE.stddev * eps
             samples["mask"], samples["E"] = mask, E  # (no dists["q_E"] in this mode: no caller of the inference path reads it)
 
-        dists["q_qc_E"] = self.qc_encoder(self.qc_encoder_input.unsqueeze(0).expand(P, -1, -1))
+        if self._qc_dist_cache is not None and not torch.is_grad_enabled():
+            qm, qs = self._qc_dist_cache  # (Q, L) each: the encoder's input is the same ones(Q, L) for every particle
+            dists["q_qc_E"] = torch.distributions.Normal(qm.unsqueeze(0).expand(P, -1, -1), qs.unsqueeze(0).expand(P, -1, -1))
+        else:
+            dists["q_qc_E"] = self.qc_encoder(self.qc_encoder_input.unsqueeze(0).expand(P, -1, -1))
         samples["qc_E"] = cv["qc_E"] if "qc_E" in cv else rsample(dists["q_qc_E"], "eps_qc_E")
 
         if X is not None and D is not None and qc is not None:
