@@ -276,6 +276,14 @@ __global__ __launch_bounds__(64 * WS * WS * WK) void gemm_f32_kernel(const GemmP
       }
       // CH elements per batch: all 16 at once costs ~80 more VGPRs (a wave of occupancy on the large kernels)
       constexpr int CH = WS == 2 ? 1 : 8;
+      // A lane's 16 elements share their column: with CH = 1 the bias is one load per lane, not one per element
+      // (element by element, every store waited for its own bias load: 16 dependent L2 round trips per wave)
+      GemmParams pe = p;
+      float bcol = 0.f;
+      if (CH == 1 && p.bias && !p.extra_col) {
+        bcol = p.bias[col < p.N ? col : 0];
+        pe.bias = nullptr;
+      }
 #pragma unroll
       for (int e0 = 0; e0 < 16; e0 += CH) {
         int rows[CH], cols[CH];
@@ -286,9 +294,9 @@ __global__ __launch_bounds__(64 * WS * WS * WK) void gemm_f32_kernel(const GemmP
           rows[e] = row0 + (wm * TM + i) * 32 + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2) + 4 * lh;
           cols[e] = col;
           ok[e] = rows[e] < p.M;
-          v[e] = acc[i][j][e0 + e];
+          v[e] = acc[i][j][e0 + e] + bcol;
         }
-        epilogue_batch<CH>(p, rows, cols, ok, v);
+        epilogue_batch<CH>(pe, rows, cols, ok, v);
       }
     }
 }

@@ -364,7 +364,8 @@ void head_fwd(Ctx& c, const cradle_mlp_ptrs& m, int M, int H, int Nout, const fl
 const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_ptrs& g, int M, int H, int Nout,
                             const float* dout, float* const* y, float* const* r, float* const* Gb, float* const* da,
                             int q, int wq, int wq2, hipEvent_t ev_dout = nullptr, hipEvent_t* ev_done = nullptr,
-                            void* ev_head_done = nullptr, int layers_per_fork = 0, int ld_dout = 0) {
+                            void* ev_head_done = nullptr, int layers_per_fork = 0, int ld_dout = 0,
+                            hipEvent_t ev_head_also = nullptr) {
   // ld_dout > Nout: rows of dout padded to a multiple of 4 with zeros (the decoder's d logits)
   if (ld_dout <= 0) ld_dout = Nout;
   const int n = m.n_layers;
@@ -378,7 +379,10 @@ const float* head_trunk_bwd(Ctx& c, const cradle_mlp_ptrs& m, const cradle_mlp_p
       c.wait(wq, ev_dout);
     }
     c.gemm(GEMM_TN, p, wq);
-    // the output layer's gradients have been enqueued, all of them on `wq`: the event goes there
+    // the output layer's gradients have been enqueued, all of them on `wq`: the event goes there -- behind
+    // `ev_head_also`, if given: what else the caller counts to the same gradient bucket and makes on another stream
+    // (the decoder's d log_concentration: K1's column sum on stream 2)
+    if (ev_head_done && ev_head_also) c.wait(wq, ev_head_also);
     if (ev_head_done && !c.rc && hipEventRecord((hipEvent_t)ev_head_done, c.st[wq]) != hipSuccess) {
       cradle_set_error("elbo_step: bucket event record failed");
       c.rc = CRADLE_ERR_HIP;
@@ -708,8 +712,14 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   // pass; the same event forks the output layer's weight gradient to stream 1
   hipEvent_t ev_k1 = c.record(0);
   c.wait(2, ev_k1);
+  // (d log_c first: it lies in the first gradient bucket -- output layer + log_concentration -- whose event, when a
+  // data-parallel caller asked for one, must not fire before this sum has been written)
+  hipEvent_t ev_dlogc = nullptr;
+  if (d.compute_grads) {
+    STEP(nb_dlogc_reduce(w.nbws, N * cradle_nb_particle_split(P, N), Gp, d.d_log_concentration, 0, s2, G));
+    if (d.ev_bucket[0]) ev_dlogc = c.record(2);
+  }
   STEP(gaussE_fwd(w.headsE, nz_E, d.p_E_loc, d.p_E_scale, w.E, w.sdE, w.SE, PP, T, Tc, w.plan.tmap, L, s2));
-  if (d.compute_grads) STEP(nb_dlogc_reduce(w.nbws, N * cradle_nb_particle_split(P, N), Gp, d.d_log_concentration, 0, s2, G));
   STEP(finalize_loss(w.recon, w.cp.wrec, w.ltz, w.klrow, w.Smask, w.SE, w.Sq, w.cp.cwc, w.cp.cwq, d.beta, P, N, Tc, Q,
                      d.flags, d.out, s2));
   if (!d.compute_grads) {
@@ -724,7 +734,7 @@ int run_step(const cradle_step_desc& d, Work& w, Ctx& c) {
   PROBE(10);
   hipEvent_t ev_dec = nullptr;
   const float* da0d = head_trunk_bwd(c, d.dec, d.d_dec, PN, Hd, G, w.logits, w.yd, w.rd, w.Gd, w.dad, 0, 1, 2, ev_k1,
-                                     &ev_dec, d.ev_bucket[0], 0, Gp);
+                                     &ev_dec, d.ev_bucket[0], 0, Gp, ev_dlogc);
   if (c.rc) return c.rc;
   PROBE(11);
   if (!ev_dec) ev_dec = c.record(0);
