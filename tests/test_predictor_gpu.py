@@ -147,13 +147,18 @@ def _sampler_inputs(P, C, G, seed=0):
     return logits, log_c, lib
 
 
-def test_sampler_moments_and_pmf():
+@pytest.mark.parametrize("logc_shift", [0.0, -3.0])
+def test_sampler_moments_and_pmf(logc_shift):
+    """logc_shift = -3: concentrations around 0.05, so that most genes of a row take the Gamma -> Poisson composition
+    (rate < 1/4) -- more than half of them, which is where the kernel draws them in one pass instead of re-queueing
+    the small Poisson rates (sampler.hip: 2 * n_queued > G)."""
     from scipy.stats import nbinom
 
     from cradle_vae_amd import ops
 
     P, C, G = 8192, 3, 64
     logits, log_c, lib = _sampler_inputs(P, C, G)
+    log_c = log_c + logc_shift
     consts = ops.nb_gene_consts(log_c)
     sums, x = ops.nb_sample_accumulate(logits, lib, consts, P, C, seed=1234, return_samples=True)
     x = x.reshape(P, C, G).double().cpu()
@@ -175,9 +180,15 @@ def test_sampler_moments_and_pmf():
     # (NegBinomial inversion for rate >= 1/4, Gamma -> Poisson below): extremes and the two nearest 1/4
     flat = rate.flatten()
     above, below = torch.nonzero(flat >= 0.25).flatten(), torch.nonzero(flat < 0.25).flatten()
-    assert len(above) > 10 and len(below) > 10
-    picks = [above[flat[above].argmax()], above[flat[above].argmin()], below[flat[below].argmax()],
-             below[flat[below].argmin()], above[len(above) // 2], below[len(below) // 2]]
+    if logc_shift == 0.0:
+        assert len(above) > 10 and len(below) > 10
+    else:
+        assert float((rate < 0.25).float().mean(dim=1).min()) > 0.5  # every row: the one-pass form
+    picks = []
+    for grp in (above, below):
+        if len(grp) >= 3:
+            picks += [grp[flat[grp].argmax()], grp[flat[grp].argmin()], grp[len(grp) // 2]]
+    assert len(picks) >= 3
     for (t, g) in [(int(i) // G, int(i) % G) for i in picks]:
         xs = x[:, t, g].numpy().astype(np.int64)
         kmax = int(np.quantile(xs, 0.995)) + 1
