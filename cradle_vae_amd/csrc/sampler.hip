@@ -108,6 +108,16 @@ __device__ __noinline__ float sample_gamma_poisson(float c, float rate, Philox p
   return sample_poisson(lam, ph, gene, row, draw, inv_tab);
 }
 
+// First phase of the queued composition: the Gamma draw, and the Poisson draw at once when its rate is 10 or more
+// (PTRS).  Returns the count (>= 0), or -(1 + lam) for a rate lam below kPoisSearchMax, which the caller re-queues
+// for the search.  Not inlined, like sample_gamma_poisson: its registers must not count against the gene loop's.
+__device__ __noinline__ float sample_gamma_stage(float c, float rate, Philox ph, uint32_t gene, uint32_t row) {
+  uint32_t draw = 0;
+  const float lam = sample_gamma(c, ph, gene, row, draw) / rate;
+  if (lam < kPoisSearchMax) return -1.0f - lam;
+  return sample_poisson_ptrs(lam, ph, gene, row, draw);
+}
+
 // NegBinomial(c, rate) by inversion (sequential search upwards from 0).  Usable where
 //   rate >= kInvRateMin            the geometric tail (1+rate)^-k is below fp32 resolution long before
 //                                  the iteration cap, and
@@ -267,14 +277,9 @@ __global__ __launch_bounds__(NT) void nb_sample_accumulate_kernel(const float* _
         // all branches whenever its lanes differ -- they always do.)
         for (int i = tid; i < n_queued; i += NT) {
           const int g = queue[i];
-          uint32_t draw = 0;
-          const float lam = sample_gamma(gene_consts[g], ph, (uint32_t)g, row, draw) / slot[g];
-          if (lam < kPoisSearchMax) {
-            slot[g] = lam;
-            queue[G - 1 - atomicAdd(&queued_b, 1)] = g;
-          } else {
-            slot[g] = sample_poisson_ptrs(lam, ph, (uint32_t)g, row, draw);
-          }
+          const float r = sample_gamma_stage(gene_consts[g], slot[g], ph, (uint32_t)g, row);
+          slot[g] = r < 0.f ? -1.0f - r : r;
+          if (r < 0.f) queue[G - 1 - atomicAdd(&queued_b, 1)] = g;
         }
         __syncthreads();
         const int n_b = queued_b;
