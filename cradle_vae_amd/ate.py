@@ -13,6 +13,7 @@ they are dealt round-robin to the ranks and the sums meet in one all-reduce.
 from __future__ import annotations
 
 import contextlib
+import os
 
 from typing import Dict, List, Literal, Optional, Sequence
 
@@ -77,7 +78,25 @@ def estimate_model_average_treatment_effect(
     kmax = max(1, int((D_all != 0).sum(dim=1).max().item()))
     plan = F_hip.DosagePlan(D_all, kmax) if kmax <= 64 else None
     share_z = dosage_independent_variables is not None and "z_basal" in dosage_independent_variables
-    gene_consts = ops.nb_gene_consts(model.decoder.log_concentration.detach())
+    # Gene order of the decoder's output layer for this call.  K9 searches a gene's count upwards from 0, a wave's 64 lanes
+    # side by side, each loop as long as its slowest lane: the genes a wave holds should be alike in expected count.  Their
+    # order in the data is arbitrary, so the output layer's rows (and log_concentration) are permuted by the mean logit
+    # over a fixed probe set of basal states -- seeded by `seed`, not by the chunk: every rank and every split of the
+    # particles uses the same order, and with it the same draws -- and the sums are put back in the data's order at the end.
+    dec = model.decoder
+    lin = dec.normalized_mean_decoder[0]
+    perm = None
+    # (a wave's vector slot covers 256 consecutive genes: below that there is nothing to sort apart)
+    sort_env = os.environ.get("CRADLE_ATE_SORT_GENES", "1")  # "0": off; "2": always, for the mean "sampler" too (tests)
+    if (sampler == "nb" and sort_env != "0" and G > 256) or sort_env == "2":
+        pg = torch.Generator(device=device).manual_seed((seed * 1000003 + 999983) & (2**63 - 1))
+        zp = torch.cat([torch.randn((256, L), device=device, generator=pg), torch.zeros((256, 2 * L), device=device)], dim=-1)
+        score = F_hip.linear(dec.mlp(zp), lin.weight, lin.bias)[:, :G].mean(dim=0)
+        perm = torch.argsort(score)
+    W_out = lin.weight.detach() if perm is None else lin.weight.detach()[perm].contiguous()
+    b_out = lin.bias.detach() if perm is None else lin.bias.detach()[perm].contiguous()
+    log_c = dec.log_concentration.detach()
+    gene_consts = ops.nb_gene_consts(log_c if perm is None else log_c[perm].contiguous())
     sums_rows = torch.zeros((C, (G + 3) & ~3), device=device, dtype=torch.float32)  # the sampler's row length
     sums = sums_rows[:, :G]
 
@@ -122,10 +141,14 @@ def estimate_model_average_treatment_effect(
                 off = (F_hip.dosage_matmul(plan.rows(s0, s1), EM, c) if plan is not None
                        else F_hip.dense_dosage_matmul(D_all[s0:s1], EM, c))
                 z_good = torch.cat([z, off, torch.zeros((c, n, L), device=device)], dim=-1)  # model.py:121
-                p_x_good = model.decoder(z_good, lib)
+                logits = F_hip.linear(dec.mlp(z_good.reshape(c * n, -1)), W_out, b_out)  # model.decoder (mlp.py:145-154)
                 call_seed = (seed * 7919 + ci) * 4099 + s0
                 ops.nb_sample_accumulate(
-                    p_x_good.logits, lib, gene_consts, c, n, sums=sums[s0:s1], method=method, sampler=sampler, seed=call_seed)
+                    logits, lib, gene_consts, c, n, sums=sums[s0:s1], method=method, sampler=sampler, seed=call_seed)
     parallel.allreduce_sum_(sums_rows, world)
+    if perm is not None:  # back to the data's gene order
+        ordered = torch.empty_like(sums)
+        ordered[:, perm] = sums
+        sums = ordered
     means = sums / n_particles  # :199-200
     return (means[1:] - means[:1]).cpu().numpy()

@@ -414,6 +414,42 @@ def test_ate_gather_and_slab_path_equals_dense_oracle(method, G, monkeypatch):
     np.testing.assert_allclose(slabbed, whole, rtol=1e-6, atol=1e-6 * scale)  # slabs change no row's arithmetic
 
 
+def test_ate_gene_order_of_the_sampler_changes_no_effect(monkeypatch):
+    """ate.py hands the decoder's output layer to the sampler with its genes ordered by expected count (G > 256) and puts
+    the sums back in the data's order: with the deterministic "sampler" the ordered call equals the plain one to fp32
+    rounding, both methods; with counts drawn the two differ only by their draws (same distribution: their difference is
+    within the Monte-Carlo error of either), and the ordered call is reproducible and independent of the chunking of the
+    particles over ranks (the order is a function of the parameters and the seed alone)."""
+    from cradle_vae_amd.predictor import cradle_vae_Predictor
+
+    T, G, L, H, n_alt, c = 24, 301, 16, 32, 12, 64
+    cfg, params, D_ctl, D_alt = _ate_setup(T, G, L, H, n_alt, seed=3)
+    case = dict(cfg=cfg, params={k: v.to(DEV) for k, v in params.items()})
+    lm = build_loss_module(case)
+    pred = cradle_vae_Predictor(lm.model, lm.guide)
+    lib = 2e3 * torch.ones(1)
+    for method in ("mean", "perturbseq"):
+        kw = dict(dosages_alt=D_alt, dosages_control=D_ctl, quality=torch.ones(1, 1), method=method, n_particles=1024,
+                  condition_values=dict(library_size=lib), batch_size=c, seed=4)
+        monkeypatch.setenv("CRADLE_ATE_SORT_GENES", "0")
+        plain = pred.estimate_average_treatment_effects(sampler="mean", **kw).X
+        drawn_plain = pred.estimate_average_treatment_effects(sampler="nb", **kw).X
+        monkeypatch.setenv("CRADLE_ATE_SORT_GENES", "2")
+        ordered = pred.estimate_average_treatment_effects(sampler="mean", **kw).X
+        monkeypatch.setenv("CRADLE_ATE_SORT_GENES", "1")  # the default: counts drawn, G > 256 -> ordered
+        drawn = pred.estimate_average_treatment_effects(sampler="nb", **kw).X
+        drawn_again = pred.estimate_average_treatment_effects(sampler="nb", **kw).X
+        scale = float(np.abs(plain).max())
+        # (an effect is a difference of two means of order 10: 1e-5 of the effects' scale is fp32 rounding of those means)
+        np.testing.assert_allclose(ordered, plain, rtol=0, atol=1e-5 * scale)
+        assert np.array_equal(drawn, drawn_again) and not np.array_equal(drawn, drawn_plain)
+        # both sampled estimates scatter around the mean-sampler's value alike (1024 particles)
+        e1, e0 = drawn - plain, drawn_plain - plain
+        if method == "mean":  # (perturbseq: the transform of a draw is not the transform of its mean)
+            assert abs(e1.mean()) < 4 * e0.std() / np.sqrt(e0.size) + 1e-3 * scale, (e1.mean(), e0.std())
+        assert 0.7 < e1.std() / e0.std() < 1.4, (e1.std(), e0.std())
+
+
 def test_ate_with_ten_thousand_treatments_fits_in_two_gigabytes():
     """BASELINE config 5's predictor shape: T = 10 000 treatments, G = 8000 genes, 128-particle chunks.  As the
     reference writes it this needs a (128 * 10 000) x 10 100 one-hot encoder input (52 GB) and a dense
