@@ -362,8 +362,9 @@ def data_parallel_setup(lm, batch, shape, world, rank, dev_index, device, args):
     """N > 1, before the warm-up: (1) every rank reports its device through one all-gather -- the first collective of
     the run, so a communicator that does not span the ranks fails here, by name; (2) unless the environment pins it,
     the gradient-exchange form is MEASURED instead of assumed: a few steps with one bucket after the step and with
-    the output layer's bucket reduced under the rest of the backward pass (CRADLE_BUCKETS = 1 / 2, trainer.TrainStep),
-    the faster one (max over ranks) is what the timed region runs.  One-rank emulation could not settle this
+    the output layer's bucket reduced under the rest of the backward pass (CRADLE_BUCKETS = 1 / 2), each as
+    reduce-scatter + sharded Adam + all-gather and as all-reduce + full Adam (CRADLE_GRAD_SYNC, trainer.TrainStep);
+    the fastest of the four (max over ranks) is what the timed region runs.  One-rank emulation could not settle this
     (the overlapped form stalls there); the ranks decide from the same all-reduced numbers."""
     import torch.distributed as dist
 
@@ -378,29 +379,35 @@ def data_parallel_setup(lm, batch, shape, world, rank, dev_index, device, args):
         info["buckets"] = os.environ.get("CRADLE_BUCKETS", "1")
         info["chosen_by"] = "environment"
         return info
+    # candidates: buckets x exchange form (reduce-scatter + sharded Adam + all-gather, or all-reduce + full Adam on
+    # every rank); an exchange form pinned by the environment is not varied
+    syncs = [os.environ["CRADLE_GRAD_SYNC"]] if "CRADLE_GRAD_SYNC" in os.environ else ["rs_ag", "allreduce"]
     timings = {}
-    for nb in ("1", "2"):
-        os.environ["CRADLE_BUCKETS"] = nb
-        st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=world)
-        if st.fused is None:
-            break
-        for _ in range(3):
-            st(batch, n_particles=shape.n_particles)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            st(batch, n_particles=shape.n_particles)
-        torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
-        parallel._all_reduce(t, op=dist.ReduceOp.MAX)
-        timings[nb] = float(t) / 10 * 1e3
-        trace(f"gradient exchange with CRADLE_BUCKETS={nb}: {timings[nb]:.3f} ms/step")
-        del st
-    best = min(timings, key=timings.get) if timings else "1"
-    os.environ["CRADLE_BUCKETS"] = best
-    info.update(buckets=best, chosen_by="measured before the warm-up (10 steps each, max over ranks)",
-                ms_per_step_by_buckets=timings)
+    for sync in syncs:
+        for nb in ("1", "2"):
+            os.environ["CRADLE_BUCKETS"], os.environ["CRADLE_GRAD_SYNC"] = nb, sync
+            st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0, world_size=world)
+            if st.fused is None:
+                break
+            if st.grad_sync != sync:  # (a world size the arena's segments do not divide by: rs_ag falls back)
+                continue
+            for _ in range(3):
+                st(batch, n_particles=shape.n_particles)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                st(batch, n_particles=shape.n_particles)
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            parallel._all_reduce(t, op=dist.ReduceOp.MAX)
+            timings[f"{sync}/{nb}"] = float(t) / 10 * 1e3
+            trace(f"gradient exchange {sync} with CRADLE_BUCKETS={nb}: {timings[f'{sync}/{nb}']:.3f} ms/step")
+            del st
+    best = min(timings, key=timings.get) if timings else f"{syncs[0]}/1"
+    os.environ["CRADLE_GRAD_SYNC"], os.environ["CRADLE_BUCKETS"] = best.split("/")
+    info.update(buckets=best.split("/")[1], chosen_by="measured before the warm-up (10 steps each, max over ranks)",
+                ms_per_step_by_sync_and_buckets=timings)
     return info
 
 
