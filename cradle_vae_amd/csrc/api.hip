@@ -19,7 +19,7 @@ extern "C" {
 
 const char* cradle_last_error(void) { return g_last_error; }
 
-int cradle_abi_version(void) { return 8; }
+int cradle_abi_version(void) { return 9; }
 
 // Layout of the descriptor structs as THIS library was compiled: out[0] = sizeof, out[1..] = offsetof of every
 // field in declaration order.  Returns the number of entries (or -1: unknown struct / buffer too small).

@@ -632,6 +632,48 @@ int mask_fwd(const float* logits, const float* u, const float* p_mask_probs, flo
   return CRADLE_OK;
 }
 
+// The sample alone, for the module path's inference calls (guide.forward under no_grad: ATE, IWELBO, observation
+// sampling): mask[p, t, :] of treatments t0 .. t0 + Ts - 1 from logits (T, L) and uniforms u (P, Ts, L).  Same
+// expressions as mask_fwd_kernel: same bits.  One thread per 4 (or 1) elements.
+template <int V>
+__global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restrict__ logits, const float* __restrict__ u,
+                                                          float tau, float* __restrict__ mask, int64_t n, int64_t TsL) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+  if (i >= n) return;
+  float lgv[V], uv[V], mv[V];
+  ldv<V>(logits + i % TsL, lgv);
+  ldv<V>(u + i, uv);
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const float p = clamp_probs(sigmoidf_(sanitize(lgv[e])));
+    const float lq = logf(p) - log1pf(-p);
+    const float uu = clamp_probs(uv[e]);
+    const float y = (logf(uu) - log1pf(-uu) + lq) / tau;
+    mv[e] = rintf(clamp_probs(sigmoidf_(y)));
+  }
+  stv<V>(mask + i, mv);
+}
+
+// out = nan_to_num(mean_raw) + sqrt(nan_to_num(|exp(lv_raw) + 1e-4|)) * eps  (mlp.py:131-141 + Normal.rsample): the
+// Gaussian head's draw of the module path's inference calls; gauss_vals / gauss_draw as everywhere else.
+template <int V>
+__global__ __launch_bounds__(256) void gauss_sample_kernel(const float* __restrict__ mean_raw, int64_t ld_mean,
+                                                           const float* __restrict__ lv_raw, int64_t ld_lv,
+                                                           const float* __restrict__ eps, float* __restrict__ out,
+                                                           int64_t rows, int L) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+  if (i >= rows * L) return;
+  const int64_t r = i / L;
+  const int l = (int)(i % L);
+  float mv[V], lv[V], ev[V], ov[V];
+  ldv<V>(mean_raw + r * ld_mean + l, mv);
+  ldv<V>(lv_raw + r * ld_lv + l, lv);
+  ldv<V>(eps + i, ev);
+#pragma unroll
+  for (int e = 0; e < V; ++e) ov[e] = gauss_draw(gauss_vals(mv[e], lv[e]), ev[e]);
+  stv<V>(out + i, ov);
+}
+
 // d loss / d q_mask_logits.  dmask_a/dmask_b: gradients reaching the hard sample from mask*E and
 // from the embedding encoder's input; coefT[t] = -cw[t]/(P N) weights the log-ratio term of the
 // main pass (particles pp < P).  Straight-through: the hard sample's gradient lands on the soft
@@ -1427,3 +1469,40 @@ int finalize_loss(const float* recon, const float* wrec, const float* ltz, const
 }
 
 }  // namespace cradle
+
+
+extern "C" {
+
+int cradle_mask_sample(const float* logits, const float* u, float tau, float* mask, int P, int Ts, int L,
+                       hipStream_t stream) {
+  using namespace cradle;
+  CRADLE_CHECK_ARG(logits && u && mask && P > 0 && Ts > 0 && L > 0 && tau > 0.f, "mask_sample: bad arguments");
+  const int64_t TsL = (int64_t)Ts * L, n = (int64_t)P * TsL;
+  if (L % 4 == 0 && aligned16(logits) && aligned16(u) && aligned16(mask))
+    hipLaunchKernelGGL(mask_sample_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, logits, u, tau, mask,
+                       n, TsL);
+  else
+    hipLaunchKernelGGL(mask_sample_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, logits, u, tau, mask, n,
+                       TsL);
+  CRADLE_CHECK_LAUNCH("mask_sample_kernel");
+  return CRADLE_OK;
+}
+
+int cradle_gauss_sample(const float* mean_raw, int64_t ld_mean, const float* log_var_raw, int64_t ld_log_var,
+                        const float* eps, float* out, int64_t rows, int L, hipStream_t stream) {
+  using namespace cradle;
+  CRADLE_CHECK_ARG(mean_raw && log_var_raw && eps && out && rows > 0 && L > 0 && ld_mean >= L && ld_log_var >= L,
+                   "gauss_sample: bad arguments");
+  const int64_t n = rows * L;
+  if (L % 4 == 0 && ld_mean % 4 == 0 && ld_log_var % 4 == 0 && aligned16(mean_raw) && aligned16(log_var_raw) &&
+      aligned16(eps) && aligned16(out))
+    hipLaunchKernelGGL(gauss_sample_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, mean_raw, ld_mean,
+                       log_var_raw, ld_log_var, eps, out, rows, L);
+  else
+    hipLaunchKernelGGL(gauss_sample_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mean_raw, ld_mean,
+                       log_var_raw, ld_log_var, eps, out, rows, L);
+  CRADLE_CHECK_LAUNCH("gauss_sample_kernel");
+  return CRADLE_OK;
+}
+
+}  // extern "C"

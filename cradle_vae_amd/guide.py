@@ -4,6 +4,7 @@ correlated_normal_guide.py:18-215) on the HIP kernels."""
 from __future__ import annotations
 
 import contextlib
+import os
 
 from dataclasses import dataclass
 from typing import Dict, Literal, Optional, Tuple
@@ -12,6 +13,7 @@ import torch
 from torch import nn
 
 from . import functional as F_hip
+from . import ops
 from .distributions import GumbelSoftmaxBernoulliStraightThrough
 from .mlp import get_likelihood_mlp
 
@@ -96,9 +98,17 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
         self.dense_dosage_matmul = False
         self.dosage_overflow = None
         self._qc_dist_cache = None
+        self._temp_cache = None
 
     def get_var_keys(self):
         return ["z_basal", "E", "mask", "qc_E"]
+
+    def _temperature_value(self) -> float:
+        """gs_temperature as a host float, read from the device once per value (a buffer: load_state_dict may change it)."""
+        key = (self.gs_temperature.data_ptr(), self.gs_temperature._version)
+        if self._temp_cache is None or self._temp_cache[0] != key:
+            self._temp_cache = (key, float(self.gs_temperature))
+        return self._temp_cache[1]
 
     @contextlib.contextmanager
     def frozen_qc_dist(self):
@@ -163,7 +173,36 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
         slab = T
         if not torch.is_grad_enabled() and logits.is_cuda and P * T > MAX_PLATED_ROWS:
             slab = max(1, MAX_PLATED_ROWS // P)
-        if slab >= T:
+        # inference calls on the GPU draw q(M) and q(E|M) through one launch each (ops.mask_sample / gauss_sample: the
+        # fused step's own expressions) instead of ~25 element-wise ones; CRADLE_FUSED_DRAWS=0 keeps the torch form
+        fused_draws = (not torch.is_grad_enabled() and logits.is_cuda and logits.dtype == torch.float32
+                       and os.environ.get("CRADLE_FUSED_DRAWS", "1") != "0")
+        if fused_draws:
+            slab = min(slab, T)
+            whole = slab >= T
+            mask = cv["mask"] if "mask" in cv else (None if whole else torch.empty((P, T, L), device=logits.device))
+            E = cv["E"] if "E" in cv else (None if whole else torch.empty((P, T, L), device=logits.device))
+            temp = self._temperature_value()
+            for t0 in range(0, T, slab):
+                t1 = min(T, t0 + slab)
+                if "mask" not in cv:
+                    m_slab = ops.mask_sample(logits[t0:t1], uniforms(t0, t1), temp)
+                    if whole:
+                        mask = m_slab
+                    else:
+                        mask[:, t0:t1] = m_slab
+                if "E" not in cv:
+                    eps = noise["eps_E"][:, t0:t1] if "eps_E" in noise else torch.randn(
+                        (P, t1 - t0, L), device=logits.device, generator=generator)
+                    lins = self.embedding_encoder.mlp.linears()
+                    h = F_hip.onehot_linear(mask[:, t0:t1], lins[0].weight, lins[0].bias, t0)
+                    e_slab = self.embedding_encoder.sample_from_hidden(h, eps)
+                    if whole:
+                        E = e_slab
+                    else:
+                        E[:, t0:t1] = e_slab
+            samples["mask"], samples["E"] = mask, E  # (no dists["q_E"]: no caller of the inference path reads it)
+        elif slab >= T:
             if "mask" not in cv:
                 samples["mask"] = dists["q_mask"].rsample((P,), uniforms=uniforms(0, T))
             else:

@@ -63,6 +63,8 @@ PROTOTYPES = {
                                 c_stream]),
     "cradle_scatter_sum": (i32, [c_float_p, i64, i64, ctypes.c_void_p, c_float_p, i32, i32, i32, i32, i32, c_float_p, i64,
                                  i64, c_stream]),
+    "cradle_mask_sample": (i32, [c_float_p, c_float_p, ctypes.c_float, c_float_p, i32, i32, i32, c_stream]),
+    "cradle_gauss_sample": (i32, [c_float_p, i64, c_float_p, i64, c_float_p, c_float_p, i64, i32, c_stream]),
     "cradle_elbo_step_workspace_bytes": (i64, [ctypes.c_void_p]),
     "cradle_elbo_step": (i32, [ctypes.c_void_p, c_stream]),
     "cradle_step_debug_stop_after": (None, [i32]),
@@ -105,7 +107,7 @@ PROTOTYPES = {
 }
 
 MAX_LAYERS = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class MlpPtrs(ctypes.Structure):

@@ -82,6 +82,18 @@ class GaussianLikelihoodResidualMLP(nn.Module):
         var = nan_to_num_ref(torch.abs(var.reshape(*shape[:-1], -1)))
         return torch.distributions.Normal(mean, var.sqrt(), validate_args=False)
 
+    @torch.no_grad()
+    def sample_from_hidden(self, h: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+        """forward_from_hidden(h).rsample() with the noise given, without the Normal in between: the two heads' raw
+        outputs go through ONE launch (ops.gauss_sample) instead of nine element-wise ones (inference calls)."""
+        shape = h.shape
+        z = h.reshape(-1, shape[-1])
+        for lin in self.mlp.linears()[1:]:
+            z = F_hip.linear(z, lin.weight, lin.bias, act=True, residual=z)
+        mean = F_hip.linear(z, self.mean_encoder.weight, self.mean_encoder.bias)
+        lv = F_hip.linear(z, self.log_var_encoder.weight, self.log_var_encoder.bias)
+        return ops.gauss_sample(mean, lv, eps).reshape(*shape[:-1], -1)
+
     # ---- inference form for inputs [x_shared | tail] whose first block is the same for every particle
     # (the basal encoder reads [log-standardised X | latent offset | qc offset], correlated_normal_guide.py:
     # 190-204): x W_x^T is computed once per cell and enters the (P*n)-row product of the tail as a

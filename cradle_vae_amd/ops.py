@@ -231,6 +231,35 @@ def scatter_sum(dout: torch.Tensor, idx: torch.Tensor, val: torch.Tensor, T: int
     return dtable
 
 
+def mask_sample(logits: torch.Tensor, uniforms: torch.Tensor, temperature: float) -> torch.Tensor:
+    """Hard relaxed-Bernoulli straight-through sample (no gradient): logits (Ts, L), uniforms (P, Ts, L) -> (P, Ts, L) in
+    {0, 1}; what ``GumbelSoftmaxBernoulliStraightThrough.rsample`` returns, in one launch (inference calls only)."""
+    P, Ts, L = uniforms.shape
+    if tuple(logits.shape) != (Ts, L) or not uniforms.is_cuda or uniforms.dtype != torch.float32:
+        raise hip.CradleHipError(f"mask_sample: logits {tuple(logits.shape)} / uniforms {tuple(uniforms.shape)} on {uniforms.device}")
+    lg, u = logits.detach().contiguous().float(), uniforms.contiguous()
+    out = torch.empty_like(u)
+    hip.check(hip.load().cradle_mask_sample(hip.ptr(lg), hip.ptr(u), float(temperature), hip.ptr(out), P, Ts, L, hip.stream()),
+              "mask_sample")
+    return out
+
+
+def gauss_sample(mean_raw: torch.Tensor, log_var_raw: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+    """nan_to_num(mean_raw) + sqrt(nan_to_num(|exp(log_var_raw) + 1e-4|)) * eps, all (rows, L) (rows may be strided):
+    the Gaussian head's reparameterised draw of mlp.py:131-141 in one launch (inference calls only)."""
+    L = mean_raw.shape[-1]
+    m, lv = mean_raw.reshape(-1, L), log_var_raw.reshape(-1, L)
+    e = eps.reshape(-1, L).contiguous()
+    if m.shape != lv.shape or m.shape != e.shape or m.stride(1) != 1 or lv.stride(1) != 1 or not (m.is_cuda and lv.is_cuda) \
+            or m.dtype != torch.float32 or lv.dtype != torch.float32:
+        raise hip.CradleHipError("gauss_sample: fp32 CUDA tensors of one shape with contiguous rows expected")
+    out = torch.empty((m.shape[0], L), device=m.device, dtype=torch.float32)
+    # (row-strided views -- the two halves of one head buffer -- are taken as they are: pointer + leading dimension)
+    hip.check(hip.load().cradle_gauss_sample(m.data_ptr(), m.stride(0), lv.data_ptr(), lv.stride(0), hip.ptr(e), hip.ptr(out),
+                                             m.shape[0], L, hip.stream()), "gauss_sample")
+    return out
+
+
 NT, NN, TN = 0, 1, 2
 
 

@@ -187,6 +187,22 @@ int cradle_scatter_sum(const float* dout, int64_t out_stride_p, int64_t out_stri
                        const float* ell_val, int P, int N, int kmax, int T, int L, float* dtable, int64_t stride_p,
                        int64_t stride_t, cradle_stream_t stream);
 
+/* ---- Draws of the module path's inference calls ---------------------------------------------
+ * guide.forward under no_grad (the ATE estimator once per particle chunk, IWELBO, observation sampling) draws q(M) and
+ * q(E|M), q(z_basal) through ~25 element-wise torch launches per call in the reference's form; these two are the same
+ * arithmetic in one launch each (the expressions of the fused step's own kernels: same bits).
+ *   cradle_mask_sample : relaxed-Bernoulli straight-through sample, hard value only
+ *                        (cradle_vae/models/utils/gumbel_softmax_bernoulli.py:5-17 over pyro RelaxedBernoulliStraightThrough,
+ *                        call site guides/correlated_normal_guide.py:132-141): logits (Ts, L) -- NaN/Inf read as 0
+ *                        (sanitize_tensor, :212-215) --, uniforms u (P, Ts, L), temperature tau -> mask (P, Ts, L) in {0,1}
+ *   cradle_gauss_sample: the Gaussian head's reparameterised draw (models/utils/mlp.py:131-141 + Normal.rsample at
+ *                        correlated_normal_guide.py:157,166,202-204): mean_raw, log_var_raw (rows, L) with leading
+ *                        dimensions ld_*, eps (rows, L) -> out = nan_to_num(mean) + sqrt(nan_to_num(|exp(lv) + 1e-4|)) * eps */
+int cradle_mask_sample(const float* logits, const float* u, float tau, float* mask, int P, int Ts, int L,
+                       cradle_stream_t stream);
+int cradle_gauss_sample(const float* mean_raw, int64_t ld_mean, const float* log_var_raw, int64_t ld_log_var,
+                        const float* eps, float* out, int64_t rows, int L, cradle_stream_t stream);
+
 /* ---- The fused ELBO step ---------------------------------------------------------------
  * Forward + backward of PerturbationPlatedELBOLossModule.loss
  * (cradle_vae/models/utils/loss_modules.py:54-187: guide(X,qc) -> model -> guide(cfX,1-qc),
