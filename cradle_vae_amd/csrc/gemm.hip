@@ -366,6 +366,8 @@ static bool launch_cfg(const GemmParams& p, int ws, int tm, int tn, int bk, int 
   CRADLE_GEMM_CASE(2, 1, 1, 32, 4, 1)
   CRADLE_GEMM_CASE(1, 1, 2, 32, 2, 4)
   CRADLE_GEMM_CASE(1, 2, 2, 32, 2, 4)
+  CRADLE_GEMM_CASE(2, 2, 1, 16, 2, 1)  // 128x64 / 64x128 tiles (64x32, 32x64 per wave): tools/gemm_rect_tiles.py, slower
+  CRADLE_GEMM_CASE(2, 1, 2, 16, 2, 1)
 #undef CRADLE_GEMM_CASE
   return false;
 }
