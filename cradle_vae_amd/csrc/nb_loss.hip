@@ -17,6 +17,7 @@
 #include "nb_math.h"
 
 #include <mutex>
+#include <type_traits>
 
 namespace cradle {
 
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
   // ---- per-cell, per-gene state in registers
   float4 x[VPT], c[VPT], dmain[VPT];  // dmain: sum_r grow[r] * d log p / dc
   float lg_local = 0.f;
+  float cmin = INFINITY;  // smallest concentration among this thread's genes (decides the rows' clamp-free pass)
   float gsum = 0.f;  // sum of this block's upstream row gradients (scales the digamma part)
   if (BWD)
     for (int p = ps; p < P; p += PS) gsum += grow[(int64_t)p * N + n];
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
     if (k < G4) {
       x[j] = TAIL ? mask_gene_tail(X4[k], k, Gv, 0.f) : X4[k];
       c[j] = C4[k];
+      cmin = fminf(fminf(fminf(c[j].x, c[j].y), fminf(c[j].z, c[j].w)), cmin);
       float4 dpsi = make_float4(0.f, 0.f, 0.f, 0.f);
       if (PRE) {
         if (BWD) dpsi = reinterpret_cast<const float4*>(dlogc_part + ((int64_t)n * PS + ps) * G)[k];
@@ -134,22 +137,31 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
     const float g_r = BWD ? grow[r] : 0.f;
     float tsum = 0.f, usum = 0.f;
     float4 u[VPT];
+    auto main_pass = [&](auto noclamp) {
+      constexpr bool NC = decltype(noclamp)::value;
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) {
-      const int k = j * NT + tid;
-      if (k < G4) {
-        float du;
-        tsum += nb_main_term<BWD>(cur[j].x * mu_scale, x[j].x, c[j].x, u[j].x, du);
-        if (BWD) dmain[j].x = fmaf(g_r, du, dmain[j].x);
-        tsum += nb_main_term<BWD>(cur[j].y * mu_scale, x[j].y, c[j].y, u[j].y, du);
-        if (BWD) dmain[j].y = fmaf(g_r, du, dmain[j].y);
-        tsum += nb_main_term<BWD>(cur[j].z * mu_scale, x[j].z, c[j].z, u[j].z, du);
-        if (BWD) dmain[j].z = fmaf(g_r, du, dmain[j].z);
-        tsum += nb_main_term<BWD>(cur[j].w * mu_scale, x[j].w, c[j].w, u[j].w, du);
-        if (BWD) dmain[j].w = fmaf(g_r, du, dmain[j].w);
-        if (BWD) usum += (u[j].x + u[j].y) + (u[j].z + u[j].w);
+      for (int j = 0; j < VPT; ++j) {
+        const int k = j * NT + tid;
+        if (k < G4) {
+          float du;
+          tsum += nb_main_term<BWD, NC>(cur[j].x * mu_scale, x[j].x, c[j].x, u[j].x, du);
+          if (BWD) dmain[j].x = fmaf(g_r, du, dmain[j].x);
+          tsum += nb_main_term<BWD, NC>(cur[j].y * mu_scale, x[j].y, c[j].y, u[j].y, du);
+          if (BWD) dmain[j].y = fmaf(g_r, du, dmain[j].y);
+          tsum += nb_main_term<BWD, NC>(cur[j].z * mu_scale, x[j].z, c[j].z, u[j].z, du);
+          if (BWD) dmain[j].z = fmaf(g_r, du, dmain[j].z);
+          tsum += nb_main_term<BWD, NC>(cur[j].w * mu_scale, x[j].w, c[j].w, u[j].w, du);
+          if (BWD) dmain[j].w = fmaf(g_r, du, dmain[j].w);
+          if (BWD) usum += (u[j].x + u[j].y) + (u[j].z + u[j].w);
+        }
       }
-    }
+    };
+    // cur <= 1, so no mean of this row exceeds mu_scale: where every lane's smallest c keeps c/(mu + 1e-4) above the
+    // clamp of mlp.py:163 (always, for concentrations and library sizes of this world), the wave takes the pass
+    // without it.  The test is per wave and row: same path in every run.
+    const bool no_clamp = cmin >= kRateMin * 1.0001f * (mu_scale + kMuEps);
+    if (__builtin_amdgcn_ballot_w64(!no_clamp) == 0) main_pass(std::true_type{});
+    else main_pass(std::false_type{});
     const float2 tu = block_sum2<NT>(tsum, usum, red[rbase + 2]);
     if (tid == 0) out[r] = tu.x + LG;
     if (BWD) {

@@ -90,9 +90,29 @@ __device__ __forceinline__ float nb_lgamma_term(float x, float c, float lgc, flo
 
 // Main term F(mu; x, c).  BWD also returns u = mu * dF/dmu (the softmax-Jacobian input) and
 // du = dF/dc at fixed mu.
-template <bool BWD>
+// NOCLAMP: the caller knows that rate0 = c/m >= 1e-6 for this element (the rows kernel tests it once per row and
+// wave: min c of the thread against the row's largest possible mean), so the clamp and its selects drop out, and
+// the two quotients c/m and 1/(m+c) come from ONE reciprocal, 1/(m(m+c)): the kernel is bound by its VALU work, and
+// a transcendental costs four ordinary operations (m >= 1e-4 and m + c >= 1e-4: the product is a normal float).
+template <bool BWD, bool NOCLAMP = false>
 __device__ __forceinline__ float nb_main_term(float mu, float x, float c, float& u, float& du) {
   const float m = mu + kMuEps;
+  if constexpr (NOCLAMP) {
+    const float s = m + c;
+    const float r = fast_rcp(m * s);
+    const float rate = c * (s * r);  // c / m
+    const float rmc = m * r;         // 1 / (m + c)
+    const float lr = fast_log(rate);
+    const float u1 = 1.0f + rate;
+    const float d = rate - (u1 - 1.0f);
+    const float l1p = fast_log(u1) + d * (m * rmc);  // log1p(rate), first-order correction d/u1, 1/u1 = m/(m+c)
+    if (BWD) {
+      const float t = (x - m) * rmc;
+      u = mu * rate * t;
+      du = lr - l1p - t;
+    }
+    return c * lr - (c + x) * l1p;
+  }
   const float rate0 = c * fast_rcp(m);
   const bool clamped = rate0 < kRateMin;  // torch.clamp(min=1e-6): gradient passes where rate0 >= min
   const float rate = clamped ? kRateMin : rate0;
