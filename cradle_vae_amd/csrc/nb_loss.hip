@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
   const float LG = PRE ? pre_lg[n] : block_sum<NT>(lg_local, reinterpret_cast<float*>(red[5]));
 
   // ---- walk this block's particle rows, prefetching one row ahead
-  float4 cur[VPT], nxt[VPT];
+  float4 buf_a[VPT], buf_b[VPT];
   auto load_row = [&](int p, float4* dst) {
     const float4* L4 = reinterpret_cast<const float4*>(logits + ((int64_t)p * N + n) * ld_logits);
 #pragma unroll
@@ -104,31 +104,33 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
                         : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     }
   };
-  if (ps < P) load_row(ps, nxt);
-  int it = 0;
-  for (int p = ps; p < P; p += PS, ++it) {
-#pragma unroll
-    for (int j = 0; j < VPT; ++j) cur[j] = nxt[j];
+  // One row: `cur` holds its logits, the next row's are requested into `nxt` first.  The loop below runs the rows in
+  // pairs with the two buffers trading places (no register copies between rows).  rbase: three disjoint LDS rows per
+  // row of the walk, alternating between two sets: a fast wave may start the next reduction while a slow one still
+  // reads the previous result, never the one after that.
+  auto do_row = [&](int p, int rbase, float4* cur, float4* nxt) __attribute__((always_inline)) {
     if (p + PS < P) load_row(p + PS, nxt);
-    // three disjoint LDS rows per iteration, alternating between two sets: a fast wave may start the next
-    // reduction while a slow one still reads the previous result, never the one after that
-    const int rbase = (it & 1) * 3;
 
-    // row max
+    // row max (v_max3: fmaxf alone compiles to a max plus a canonicalising max per element)
     float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) mx = fmaxf(fmaxf(fmaxf(cur[j].x, cur[j].y), fmaxf(cur[j].z, cur[j].w)), mx);
+    for (int j = 0; j < VPT; ++j) mx = max3(max3(mx, cur[j].x, cur[j].y), cur[j].z, cur[j].w);
     mx = block_max<NT>(mx, reinterpret_cast<float*>(red[rbase]));
-    // exp and row sum
-    float se = 0.f;
+    // exp and row sum: exp(l - mx) = exp2(l * log2(e) - mx * log2(e)), one fused multiply-add per element
+    const float mxs = -mx * kLog2e;
+    float2 se2 = make_float2(0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
-      cur[j].x = fast_exp(cur[j].x - mx);
-      cur[j].y = fast_exp(cur[j].y - mx);
-      cur[j].z = fast_exp(cur[j].z - mx);
-      cur[j].w = fast_exp(cur[j].w - mx);
-      se += (cur[j].x + cur[j].y) + (cur[j].z + cur[j].w);
+      cur[j].x = __builtin_amdgcn_exp2f(fmaf(cur[j].x, kLog2e, mxs));
+      cur[j].y = __builtin_amdgcn_exp2f(fmaf(cur[j].y, kLog2e, mxs));
+      cur[j].z = __builtin_amdgcn_exp2f(fmaf(cur[j].z, kLog2e, mxs));
+      cur[j].w = __builtin_amdgcn_exp2f(fmaf(cur[j].w, kLog2e, mxs));
+      se2.x += cur[j].x;
+      se2.y += cur[j].y;
+      se2.x += cur[j].z;
+      se2.y += cur[j].w;
     }
+    float se = se2.x + se2.y;
     se = block_sum<NT>(se, reinterpret_cast<float*>(red[rbase + 1]));
     const float inv_se = 1.0f / se;
     const float mu_scale = libn * inv_se;  // mu = e * lib / sum(e)
@@ -180,6 +182,11 @@ __global__ __launch_bounds__(NT) void nb_rows_kernel(
         }
       }
     }
+  };
+  if (ps < P) load_row(ps, buf_a);
+  for (int p = ps; p < P; p += 2 * PS) {
+    do_row(p, 0, buf_a, buf_b);
+    if (p + PS < P) do_row(p + PS, 3, buf_b, buf_a);
   }
 
   if (BWD) {

@@ -34,7 +34,14 @@ __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcp
 // argument here is a normal float (rates >= 1e-6, 1 + rate >= 1, counts >= 1), and an
 // exponent argument far below zero may flush to 0, which is its correct limit in a softmax
 __device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.6931471805599453f; }
-__device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(v * kLog2e); }
+// max of three in one instruction (NaN operands are passed over, like fmaxf)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 
 // log(1+r) with relative accuracy for small |r| (r > -1).
 __device__ __forceinline__ float log1p_acc(float r) {
