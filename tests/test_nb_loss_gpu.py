@@ -7,7 +7,7 @@ from oracle import cradle_oracle as co
 pytestmark = pytest.mark.gpu
 
 
-def _case(P, N, G, seed, count_scale=1.0, big_counts=False, tiny_c=False):
+def _case(P, N, G, seed, count_scale=1.0, big_counts=False, tiny_c=False, tiny_c_head=0):
     g = torch.Generator().manual_seed(seed)
     logits = 2.0 * torch.randn(P * N, G, generator=g, dtype=torch.float64)
     lam = torch.exp(-1.0 + 1.5 * torch.randn(G, generator=g, dtype=torch.float64)) * count_scale
@@ -19,6 +19,8 @@ def _case(P, N, G, seed, count_scale=1.0, big_counts=False, tiny_c=False):
     if tiny_c:  # concentrations far below a millionth of the mean: rate = c / (mu + 1e-4) sits on its clamp (mlp.py:163)
         log_c[::7] = -30.0
         log_c[3::11] = -18.0
+    if tiny_c_head:  # only the first wave of a 256-thread workgroup meets clamped genes: its pass keeps the clamp, the others' drop it
+        log_c[:tiny_c_head:3] = -30.0
     grow = torch.randn(P * N, generator=g, dtype=torch.float64)
     return logits.float().double(), X, lib, log_c.float().double(), grow.float().double()
 
@@ -50,6 +52,7 @@ def _oracle(logits, X, lib, log_c, grow, P):
         (2, 9, 1202, {}),   # the tail is masked in the kernel
         (3, 17, 5003, dict(big_counts=True)),
         (4, 24, 1000, dict(tiny_c=True)),  # the rate clamp active on real genes (K1's single-reciprocal form, nb_math.h)
+        (5, 12, 5000, dict(tiny_c_head=256)),  # ... in one wave of each workgroup only: both passes in one launch
     ],
 )
 def test_nb_logprob_matches_oracle(P, N, G, kw):
