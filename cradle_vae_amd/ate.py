@@ -27,6 +27,17 @@ MAX_ROWS_PER_LAUNCH = 1 << 16  # decoder rows (particles x conditions) per GEMM 
 MAX_LOGIT_FLOATS = 1 << 27     # ... and at most 512 MB of decoder logits at a time
 
 
+_DRAW_STREAMS = {}
+
+
+def _draw_stream(device) -> "torch.cuda.Stream":
+    """One side stream per device for the sampler launches of every call (created once: a stream is a hardware queue)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _DRAW_STREAMS:
+        _DRAW_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _DRAW_STREAMS[key]
+
+
 def _chunk_generator(device, seed: int, chunk_idx: int) -> torch.Generator:
     g = torch.Generator(device=device)
     g.manual_seed((seed * 1000003 + chunk_idx) & (2**63 - 1))
@@ -102,6 +113,11 @@ def estimate_model_average_treatment_effect(
 
     world, rank = parallel.world_and_rank()
     starts = list(range(0, n_particles, batch_size))
+    # draws beside the next decoder pass (CRADLE_ATE_OVERLAP=0: one stream; also when every launch is being timed on its
+    # own, bench.py's kernel figures)
+    draw_stream, in_flight = None, []
+    if device.type == "cuda" and os.environ.get("CRADLE_ATE_OVERLAP", "1") != "0" and ops.KERNEL_TIMING != "all":
+        draw_stream = _draw_stream(device)
     # q(qc_E)'s mean and scale once for the whole call, not once per particle chunk (guide.frozen_qc_dist)
     with guide.frozen_qc_dist() if hasattr(guide, "frozen_qc_dist") else contextlib.nullcontext():
         for ci in parallel.my_chunks(len(starts), world, rank):
@@ -143,8 +159,30 @@ def estimate_model_average_treatment_effect(
                 z_good = torch.cat([z, off, torch.zeros((c, n, L), device=device)], dim=-1)  # model.py:121
                 logits = F_hip.linear(dec.mlp(z_good.reshape(c * n, -1)), W_out, b_out)  # model.decoder (mlp.py:145-154)
                 call_seed = (seed * 7919 + ci) * 4099 + s0
-                ops.nb_sample_accumulate(
-                    logits, lib, gene_consts, c, n, sums=sums[s0:s1], method=method, sampler=sampler, seed=call_seed)
+                if draw_stream is None:
+                    ops.nb_sample_accumulate(
+                        logits, lib, gene_consts, c, n, sums=sums[s0:s1], method=method, sampler=sampler, seed=call_seed)
+                    continue
+                # The sampler is bound by its vector ALU work, the decoder by the matrix pipes: this slab's draws run
+                # on a stream of their own beside the next slab's decoder pass.  Launches on one stream keep their
+                # order, so every row of `sums` is added to in the same order as without the overlap: same numbers.
+                # At most three slabs of logits are alive (0.3 GB each at Norman's size): the host waits for the draws of
+                # the slab three back (measured: 61.0 ms with two, 59.1 with three or five, 63.0 on one stream).
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(draw_stream):
+                    draw_stream.wait_event(ready)
+                    ops.nb_sample_accumulate(
+                        logits, lib, gene_consts, c, n, sums=sums[s0:s1], method=method, sampler=sampler, seed=call_seed)
+                    drawn = torch.cuda.Event()
+                    drawn.record()
+                in_flight.append((drawn, logits))
+                del logits
+                if len(in_flight) > 2:
+                    in_flight.pop(0)[0].synchronize()
+    if draw_stream is not None:
+        torch.cuda.current_stream(device).wait_stream(draw_stream)
+        in_flight.clear()  # (stream-ordered: whatever reuses the logits' memory is enqueued behind the wait)
     parallel.allreduce_sum_(sums_rows, world)
     if perm is not None:  # back to the data's gene order
         ordered = torch.empty_like(sums)

@@ -229,7 +229,8 @@ class cradle_vae_CorrelatedNormalGuide(nn.Module):
 
         if self._qc_dist_cache is not None and not torch.is_grad_enabled():
             qm, qs = self._qc_dist_cache  # (Q, L) each: the encoder's input is the same ones(Q, L) for every particle
-            dists["q_qc_E"] = torch.distributions.Normal(qm.unsqueeze(0).expand(P, -1, -1), qs.unsqueeze(0).expand(P, -1, -1))
+            dists["q_qc_E"] = torch.distributions.Normal(  # (validate_args: its check reads the device -- a host sync per call)
+                qm.unsqueeze(0).expand(P, -1, -1), qs.unsqueeze(0).expand(P, -1, -1), validate_args=False)
         else:
             dists["q_qc_E"] = self.qc_encoder(self.qc_encoder_input.unsqueeze(0).expand(P, -1, -1))
         samples["qc_E"] = cv["qc_E"] if "qc_E" in cv else rsample(dists["q_qc_E"], "eps_qc_E")
