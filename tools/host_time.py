@@ -6,8 +6,9 @@ import torch, bench
 from cradle_vae_amd import synthetic as syn
 from cradle_vae_amd.trainer import TrainStep
 
-shape = syn.SHAPES[sys.argv[1] if len(sys.argv) > 1 else "norman"]
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+shape = syn.SHAPES[argv[0] if len(argv) > 0 else "norman"]
+steps = int(argv[1]) if len(argv) > 1 else 8
 lm, batch = bench.build(shape, "cuda:0", seed=1000)
 st = TrainStep(lm, lr=3e-4, weight_decay=1e-6, gradient_clip_norm=100.0)
 for _ in range(20):
@@ -26,3 +27,14 @@ for _ in range(10):
 host.sort(); total.sort()
 print(f"{shape.name}: host enqueue {host[len(host)//2]:.3f} ms/step (min {host[0]:.3f}), enqueue+drain {total[len(total)//2]:.3f} ms/step "
       f"over bursts of {steps} steps")
+if "--profile" in sys.argv:  # the Python side of a step, by function (the C library's launches are one ctypes call)
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(50):
+        st(batch, n_particles=shape.n_particles)
+        if _ % 6 == 5:
+            torch.cuda.synchronize()  # keep the queue short: a full queue would show up as host time
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(18)
