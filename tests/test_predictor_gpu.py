@@ -450,6 +450,29 @@ def test_ate_gene_order_of_the_sampler_changes_no_effect(monkeypatch):
         assert 0.7 < e1.std() / e0.std() < 1.4, (e1.std(), e0.std())
 
 
+def test_ate_draws_beside_the_next_decoder_pass_change_no_number(monkeypatch):
+    """ate.py launches a slab's draws on a side stream beside the next slab's decoder pass.  Launches on one stream keep
+    their order and every (condition, gene) sum is added to by that stream alone: the overlapped call returns the bits
+    of the one-stream call (CRADLE_ATE_OVERLAP=0), several slabs per chunk and several chunks, both samplers."""
+    import cradle_vae_amd.ate as ate_mod
+    from cradle_vae_amd.predictor import cradle_vae_Predictor
+
+    T, G, L, H, n_alt, c = 24, 301, 16, 32, 12, 64
+    cfg, params, D_ctl, D_alt = _ate_setup(T, G, L, H, n_alt, seed=5)
+    case = dict(cfg=cfg, params={k: v.to(DEV) for k, v in params.items()})
+    lm = build_loss_module(case)
+    pred = cradle_vae_Predictor(lm.model, lm.guide)
+    monkeypatch.setattr(ate_mod, "MAX_ROWS_PER_LAUNCH", 4 * c)  # 13 conditions in slabs of 4: four sampler launches a chunk
+    for sampler in ("nb", "mean"):
+        kw = dict(dosages_alt=D_alt, dosages_control=D_ctl, quality=torch.ones(1, 1), method="perturbseq", n_particles=5 * c,
+                  condition_values=dict(library_size=2e3 * torch.ones(1)), batch_size=c, seed=9, sampler=sampler)
+        monkeypatch.setenv("CRADLE_ATE_OVERLAP", "0")
+        one_stream = pred.estimate_average_treatment_effects(**kw).X
+        monkeypatch.setenv("CRADLE_ATE_OVERLAP", "1")
+        for _ in range(3):
+            assert np.array_equal(pred.estimate_average_treatment_effects(**kw).X, one_stream)
+
+
 def test_ate_with_ten_thousand_treatments_fits_in_two_gigabytes():
     """BASELINE config 5's predictor shape: T = 10 000 treatments, G = 8000 genes, 128-particle chunks.  As the
     reference writes it this needs a (128 * 10 000) x 10 100 one-hot encoder input (52 GB) and a dense
