@@ -422,6 +422,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--shape", default="norman")
+    ap.add_argument("--preheat-steps", type=int, default=100,
+                    help="untimed steps before the warm-up steps: brings an idle chip up to its clocks (0 = none)")
     ap.add_argument("--step-impl", default="auto", choices=["auto", "fused", "modular"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Replogle-shaped side measurement (N=1 only)")
@@ -474,6 +476,12 @@ def main():
         return stepper(batch, n_particles=shape.n_particles)
 
     trace("modules built")
+    # A chip that has idled (the seconds of set-up above) runs 10-15 % slow for its first tens of milliseconds under
+    # load (tools/first_steps.py: 1.12 ms per step falling to 0.96 over ~20 steps after 50 ms of idle): without this,
+    # a short timed region measures the clock ramp, not the step.  Untimed, outside --warmup and --steps, reported in
+    # the line as config.preheat_steps; --preheat-steps 0 turns it off.
+    for i in range(args.preheat_steps):
+        one_step(i)
     for i in range(args.warmup):
         one_step(i)
         trace(f"warmup step {i} enqueued")
@@ -561,6 +569,7 @@ def main():
                 "workload": f"{shape.name}: ELBO fwd+bwd+clip+Adam, N={N} cells/GPU, P={P}, G={G}, "
                             f"T={shape.n_treatments}, L={shape.n_latent}, H={shape.decoder_n_hidden}",
                 "step_impl": stepper.impl,
+                "preheat_steps": args.preheat_steps,
                 "decoder_variants_per_cell": V, "parallelism": f"dp{world}",
                 **({"data_parallel": dict(dp_info, grad_sync=getattr(stepper, "grad_sync", None),
                                           overlap=getattr(stepper, "overlap", None))} if dp_info else {}),
