@@ -84,6 +84,21 @@ def k1_pmc_traffic(G, N, P):
     return d.get("traffic_bytes")
 
 
+def profiled_avg_us(substr):
+    """Average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/r03_bench_kernel_stats.csv), for the reader's comparison with the live figure: the HIP events of the live
+    bracket add their own ~3 us of marker packets between dependent kernels.  None when the file is not there."""
+    import csv
+
+    path = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")
+    try:
+        with open(path) as f:
+            rows = [r for r in csv.DictReader(f) if substr in r.get("Name", "")]
+        return float(rows[0]["AverageNs"]) * 1e-3 if rows else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def k9_pmc_traffic(G, C, P):
     """HBM bytes per K9 launch (sampler + partial sums) from the committed rocprofv3 --pmc passes
     (profiles/k9_pmc.json, tools/pmc_round.sh); None if no pass was made at this launch shape."""
@@ -535,6 +550,8 @@ def main():
                 "launch_us": t_k1 * 1e6, "launches_per_step": float(V), "launches_timed": len(k1),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "copy_gbs_measured": measured_copy_gbs(device),
+                "launch_us_in_committed_rocprof_stats": profiled_avg_us("nb_rows_kernel<5, 256, true, false, true>")
+                if (G, N, P) == (5000, 512, 5) else None,
             }
         # MFMA side: minimal-form GEMM flops of the step (fwd+bwd = 3x fwd) over the whole
         # step time, against the dense fp32 matrix-core peak -- a lower bound on MFMA utilisation
