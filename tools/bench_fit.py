@@ -9,9 +9,10 @@ from cradle_vae_amd.guide import ObservationNormalizationStatistics
 from cradle_vae_amd.models.utils.perturbation_lightning_module import TrainConfigPerturbationLightningModule
 from cradle_vae_amd.trainer import fit
 
-shape = syn.SHAPES[sys.argv[1] if len(sys.argv) > 1 else "norman"]
-n_cells = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
-epochs = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+shape = syn.SHAPES[argv[0] if len(argv) > 0 else "norman"]
+n_cells = int(argv[1]) if len(argv) > 1 else 32768
+epochs = int(argv[2]) if len(argv) > 2 else 2
 dev = "cuda:0"
 data = syn.make_batch(dataclasses.replace(shape, n_cells=n_cells), seed=2)
 ds = SCRNASeqTensorPerturbationDataset(data["X"], data["D"], data["qc"], data["cfX"])
@@ -42,3 +43,11 @@ dt = time.perf_counter() - t0
 steps = hist[-1]["steps"]
 print(f"{shape.name} fit: {steps} steps of {shape.n_cells} cells in {dt*1e3:.1f} ms = {steps*shape.n_cells/dt:.0f} cells/s "
       f"({dt/steps*1e3:.3f} ms/step); train/loss {hist[0]['train/loss']:.2f} -> {hist[-1]['train/loss']:.2f}")
+if "--profile" in sys.argv:  # where the host's time goes in the loop
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    fit(mod, train, None, max_epochs=1, gradient_clip_val=100.0)
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(16)
